@@ -1,0 +1,72 @@
+// Shared device/host helpers for libfavit (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "favit.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define FAVIT_WAVE 64
+
+#define FAVIT_CHECK_LAUNCH()                         \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) return FAVIT_ERR_LAUNCH;  \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename T> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr int value = FAVIT_F32; };
+template <> struct dtype_of<bf16_t> { static constexpr int value = FAVIT_BF16; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// exact-erf GELU and its derivative (nn.GELU() default, models/vit.py:120)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// Counter-based RNG for dropout: one 32-bit draw per (seed, index); the same draw is
+// recomputed in backward, so no mask is stored.  (splitmix64 finaliser)
+__device__ __forceinline__ uint32_t favit_rand_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+// keep with probability 1-p
+__device__ __forceinline__ bool favit_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+  return favit_rand_u32(seed, idx) >= thresh;
+}
+static inline uint32_t dropout_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t <= 0) return 0u;
+  if (t >= 4294967295.0) return 4294967295u;
+  return (uint32_t)t;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,578 @@
+// MHLA: windowed "latent" attention of models/mhla.py for gfx950.
+//
+//  * favit_mhla_fold_{fwd,bwd}: latent_proj (one Linear(hd,hd) shared by K, V and all heads,
+//    mhla.py:41,105-106) folded into the qkv projection weights, and the map of the folded
+//    gradients back onto qkv.{weight,bias} / latent_proj.{weight,bias}.
+//  * favit_mhla_attn_{fwd,bwd}: the banded attention core.  The reference materialises
+//    2 x [B,H,L,W,hd] gathered windows (mhla.py:117-126); here a workgroup stages the K~/V~
+//    rows of its row block (+ halo, + the two "wrap" edges that the pad rule of
+//    mhla.py:72-79 makes reachable) in LDS once, 8 lanes share one query row (hd/8 dims
+//    each), the W scores are reduced with wave shuffles and the softmax runs in registers.
+//    HBM traffic is the algorithmic 4*B*L*D*e bytes (read q,k~,v~, write o).
+//    Backward recomputes the probabilities; dK~/dV~ are gathered per key row from LDS
+//    tables of dS / P (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+// closed form of MultiHeadLatentAttention._get_window_indices (mhla.py:46-83)
+__device__ __forceinline__ int win_idx(int i, int w, int L, int W, int h) {
+  const int lo = max(0, i - h), hi = min(L, i + h + 1), n = hi - lo;
+  if (n == W) return lo + w;
+  if (lo == 0) return w < n ? w : L - 1;       // short window starting at 0: pad END with L-1
+  const int pad = W - n;
+  return w < pad ? 0 : lo + (w - pad);         // otherwise: pad FRONT with 0
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void vload(const T* p, float (&o)[N]) {
+  constexpr int BYTES = N * (int)sizeof(T);
+  constexpr int NW = BYTES / 4;
+  uint32_t w[NW];
+  if constexpr (BYTES % 16 == 0) {
+#pragma unroll
+    for (int c = 0; c < BYTES / 16; ++c) {
+      const uint4 u = reinterpret_cast<const uint4*>(p)[c];
+      w[4 * c] = u.x; w[4 * c + 1] = u.y; w[4 * c + 2] = u.z; w[4 * c + 3] = u.w;
+    }
+  } else if constexpr (BYTES == 8) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    w[0] = u.x; w[1] = u.y;
+  } else {
+    static_assert(BYTES == 4, "unsupported vector width");
+    w[0] = *reinterpret_cast<const uint32_t*>(p);
+  }
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[j] = __uint_as_float(w[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+      o[2 * j] = __uint_as_float(w[j] << 16);
+      o[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+    }
+  }
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void vstore(T* p, const float (&v)[N]) {
+  constexpr int BYTES = N * (int)sizeof(T);
+  constexpr int NW = BYTES / 4;
+  uint32_t w[NW];
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) w[j] = __float_as_uint(v[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+      const bf16_t a = (bf16_t)v[2 * j], b = (bf16_t)v[2 * j + 1];
+      w[j] = (uint32_t)__builtin_bit_cast(unsigned short, a) | ((uint32_t)__builtin_bit_cast(unsigned short, b) << 16);
+    }
+  }
+  if constexpr (BYTES % 16 == 0) {
+#pragma unroll
+    for (int c = 0; c < BYTES / 16; ++c)
+      reinterpret_cast<uint4*>(p)[c] = make_uint4(w[4 * c], w[4 * c + 1], w[4 * c + 2], w[4 * c + 3]);
+  } else if constexpr (BYTES == 8) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
+  } else {
+    *reinterpret_cast<uint32_t*>(p) = w[0];
+  }
+}
+
+__device__ __forceinline__ float sum8(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+// LDS image of rows of one [*, hd] tensor: a contiguous "main" run of rows plus the head
+// rows [0, head_n) and the tail rows [tail_lo, L) that the wrap rule can reach.
+struct RowImage {
+  int main_lo, main_hi, n_main, head_n, tail_lo, n_rows;
+  __device__ __forceinline__ void init(int lo, int hi, int edge, int L) {
+    main_lo = max(0, lo);
+    main_hi = min(L, hi);
+    n_main = max(0, main_hi - main_lo);
+    head_n = min(edge, L);
+    tail_lo = max(0, L - edge);
+    n_rows = n_main + head_n + (L - tail_lo);
+  }
+  __device__ __forceinline__ int slot(int r) const {
+    if (r >= main_lo && r < main_hi) return r - main_lo;
+    if (r < head_n) return n_main + r;
+    return n_main + head_n + (r - tail_lo);
+  }
+  __device__ __forceinline__ int row_of_slot(int s) const {
+    if (s < n_main) return main_lo + s;
+    if (s < n_main + head_n) return s - n_main;
+    return tail_lo + (s - n_main - head_n);
+  }
+};
+
+__host__ __device__ inline int row_stride_bytes(int hd, int esz) {
+  const int rb = hd * esz;
+  return rb + ((rb % 256 == 0) ? 16 : 0);
+}
+
+// copy rows of (column block `col0`, hd wide) of src[B*L, ld] into the LDS image
+template <typename T>
+__device__ __forceinline__ void stage_rows(char* lds, const RowImage& im, const T* src, long ld, long tok0, int col0,
+                                           int hd, int rs, int tid, int nthreads) {
+  const int cpr = hd * (int)sizeof(T) / 16;       // 16-B chunks per row
+  const int total = im.n_rows * cpr;
+  for (int c = tid; c < total; c += nthreads) {
+    const int s = c / cpr, ch = c - s * cpr;
+    const int r = im.row_of_slot(s);
+    const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src + (tok0 + r) * ld + col0) + ch * 16);
+    *reinterpret_cast<uint4*>(lds + s * rs + ch * 16) = v;
+  }
+}
+
+struct AttnArgs {
+  const void* qkv;
+  const void* dout;
+  void* out;      // fwd: o ; bwd: dqkv
+  const uint8_t* mask;
+  int B, L, H, hd, W;
+  float inv_sqrt_hd;   // unused (true division is applied), kept for clarity
+  uint32_t thresh;
+  float keep_scale;
+  uint64_t seed;
+};
+
+// scores + softmax of one query row (8 lanes own the row; every lane ends with all p[w])
+template <typename T, int DPL, int WMAX>
+__device__ __forceinline__ void row_softmax(const float (&q)[DPL], const char* ldsK, const RowImage& imK, int rs,
+                                            int lane8, int i, int b, int head, const AttnArgs& a, int (&idx)[WMAX],
+                                            float (&p)[WMAX]) {
+  const int h = a.W >> 1;
+  const float sq = sqrtf((float)a.hd);
+  float m = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < WMAX; ++w) {
+    float s = -INFINITY;
+    idx[w] = 0;
+    if (w < a.W) {
+      idx[w] = win_idx(i, w, a.L, a.W, h);
+      float kf[DPL];
+      vload<T, DPL>(reinterpret_cast<const T*>(ldsK + imK.slot(idx[w]) * rs) + lane8 * DPL, kf);
+      float acc = 0.f;
+#pragma unroll
+      for (int d = 0; d < DPL; ++d) acc = fmaf(q[d], kf[d], acc);
+      s = sum8(acc) / sq;                                         // mhla.py:133 (true division)
+      if (a.mask && a.mask[((long)b * a.L + i) * a.L + idx[w]] == 0) s = -INFINITY;   // mhla.py:143
+    }
+    p[w] = s;
+    m = fmaxf(m, s);
+  }
+  float l = 0.f;
+#pragma unroll
+  for (int w = 0; w < WMAX; ++w) {
+    p[w] = (w < a.W) ? __expf(p[w] - m) : 0.f;
+    l += p[w];
+  }
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int w = 0; w < WMAX; ++w) p[w] *= inv;
+}
+
+constexpr int FWD_QPB = 64;   // query rows per workgroup (forward)
+constexpr int BWD_RB = 32;    // key/query rows per workgroup (backward)
+
+template <typename T, int DPL, int WMAX>
+__global__ __launch_bounds__(256) void mhla_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HD = 8 * DPL;
+  const int tid = threadIdx.x, lane8 = tid & 7, qs = tid >> 3;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int r0 = blockIdx.x * FWD_QPB, r1 = min(a.L, r0 + FWD_QPB);
+  const int h = a.W >> 1, D = a.H * HD;
+  const long ld = 3L * D, tok0 = (long)b * a.L;
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  const int rs = row_stride_bytes(HD, sizeof(T));
+
+  RowImage im;
+  im.init(r0 - h, r1 + h, 1, a.L);     // forward only needs keys 0 and L-1 outside the band
+  char* ldsK = smem;
+  char* ldsV = smem + im.n_rows * rs;
+  stage_rows<T>(ldsK, im, qkv, ld, tok0, D + head * HD, HD, rs, tid, 256);
+  stage_rows<T>(ldsV, im, qkv, ld, tok0, 2 * D + head * HD, HD, rs, tid, 256);
+  __syncthreads();
+
+  for (int base = r0; base < r1; base += 32) {
+    const int iq = base + qs;
+    const bool valid = iq < r1;
+    const int i = valid ? iq : r1 - 1;
+    float q[DPL];
+    vload<T, DPL>(qkv + (tok0 + i) * ld + head * HD + lane8 * DPL, q);
+    int idx[WMAX];
+    float p[WMAX];
+    row_softmax<T, DPL, WMAX>(q, ldsK, im, rs, lane8, i, b, head, a, idx, p);
+    float o[DPL];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int w = 0; w < WMAX; ++w) {
+      if (w < a.W) {
+        float pw = p[w];
+        if (a.thresh) {   // attention dropout (mhla.py:147), per window slot
+          const uint64_t e = (((uint64_t)b * a.H + head) * a.L + i) * a.W + w;
+          pw = favit_keep(a.seed, e, a.thresh) ? pw * a.keep_scale : 0.f;
+        }
+        float vf[DPL];
+        vload<T, DPL>(reinterpret_cast<const T*>(ldsV + im.slot(idx[w]) * rs) + lane8 * DPL, vf);
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) o[d] = fmaf(pw, vf[d], o[d]);
+      }
+    }
+    if (valid) vstore<T, DPL>(reinterpret_cast<T*>(a.out) + (tok0 + i) * (long)D + head * HD + lane8 * DPL, o);
+  }
+}
+
+template <typename T, int DPL, int WMAX>
+__global__ __launch_bounds__(256) void mhla_bwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HD = 8 * DPL;
+  const int tid = threadIdx.x, lane8 = tid & 7, qs = tid >> 3;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int r0 = blockIdx.x * BWD_RB, r1 = min(a.L, r0 + BWD_RB);
+  const int L = a.L, W = a.W, h = W >> 1, D = a.H * HD;
+  const long ld = 3L * D, tok0 = (long)b * L;
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  const T* dout = reinterpret_cast<const T*>(a.dout);
+  T* dqkv = reinterpret_cast<T*>(a.out);
+  const int rs = row_stride_bytes(HD, sizeof(T));
+
+  // rows whose probabilities this block needs: band rows of its keys, plus the rows that
+  // wrap onto key L-1 (rows 0..h) / key 0 (rows >= max(h+1, L-h)) if the block owns it.
+  const int qm_lo = max(0, r0 - h), qm_hi = min(L, r1 + h), n_qm = qm_hi - qm_lo;
+  const int hx_n = (r1 >= L) ? min(h + 1, L) : 0;
+  const int tx_lo = max(h + 1, L - h);
+  const int tx_n = (r0 == 0 && tx_lo < L) ? (L - tx_lo) : 0;
+  const int n_q = n_qm + hx_n + tx_n;                       // <= 32 + 2h + 2(h+1) <= 64
+  auto qrow_of = [&](int s) { return s < n_qm ? qm_lo + s : (s < n_qm + hx_n ? s - n_qm : tx_lo + (s - n_qm - hx_n)); };
+  auto qslot_of = [&](int r) { return (r >= qm_lo && r < qm_hi) ? r - qm_lo : ((hx_n > 0 && r < hx_n) ? n_qm + r : n_qm + hx_n + (r - tx_lo)); };
+
+  RowImage imK;
+  imK.init(r0 - 2 * h, r1 + 2 * h, 2 * h + 1, L);
+  char* ldsK = smem;
+  char* ldsV = ldsK + imK.n_rows * rs;
+  char* ldsQ = ldsV + imK.n_rows * rs;
+  char* ldsG = ldsQ + 64 * rs;                               // dO rows
+  float* tds = reinterpret_cast<float*>(ldsG + 64 * rs);     // [64][WMAX] dS / sqrt(hd)
+  float* tp = tds + 64 * WMAX;                               // [64][WMAX] P after dropout
+
+  stage_rows<T>(ldsK, imK, qkv, ld, tok0, D + head * HD, HD, rs, tid, 256);
+  stage_rows<T>(ldsV, imK, qkv, ld, tok0, 2 * D + head * HD, HD, rs, tid, 256);
+  {
+    const int cpr = HD * (int)sizeof(T) / 16;
+    for (int c = tid; c < n_q * cpr; c += 256) {
+      const int s = c / cpr, ch = c - s * cpr;
+      const int r = qrow_of(s);
+      *reinterpret_cast<uint4*>(ldsQ + s * rs + ch * 16) =
+          *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(qkv + (tok0 + r) * ld + head * HD) + ch * 16);
+      *reinterpret_cast<uint4*>(ldsG + s * rs + ch * 16) =
+          *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(dout + (tok0 + r) * (long)D + head * HD) + ch * 16);
+    }
+  }
+  __syncthreads();
+
+  const float sq = sqrtf((float)a.hd);
+  // ---- phase 1: per query row: P, dS; dQ for the rows this block owns ----
+  for (int pass = 0; pass < 2; ++pass) {
+    const int s = pass * 32 + qs;
+    if (pass * 32 >= n_q) break;
+    const bool valid = s < n_q;
+    const int sc = valid ? s : n_q - 1;
+    const int i = qrow_of(sc);
+    float q[DPL], g[DPL];
+    vload<T, DPL>(reinterpret_cast<const T*>(ldsQ + sc * rs) + lane8 * DPL, q);
+    vload<T, DPL>(reinterpret_cast<const T*>(ldsG + sc * rs) + lane8 * DPL, g);
+    int idx[WMAX];
+    float p[WMAX];
+    row_softmax<T, DPL, WMAX>(q, ldsK, imK, rs, lane8, i, b, head, a, idx, p);
+    float dp[WMAX], pd[WMAX];
+    float dot = 0.f;
+#pragma unroll
+    for (int w = 0; w < WMAX; ++w) {
+      dp[w] = 0.f;
+      pd[w] = 0.f;
+      if (w < W) {
+        float vf[DPL];
+        vload<T, DPL>(reinterpret_cast<const T*>(ldsV + imK.slot(idx[w]) * rs) + lane8 * DPL, vf);
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) acc = fmaf(g[d], vf[d], acc);
+        float t = sum8(acc);                       // d(P_dropped)[w]
+        float keep = 1.f;
+        if (a.thresh) {
+          const uint64_t e = (((uint64_t)b * a.H + head) * L + i) * W + w;
+          keep = favit_keep(a.seed, e, a.thresh) ? a.keep_scale : 0.f;
+        }
+        pd[w] = p[w] * keep;
+        dp[w] = t * keep;
+        dot = fmaf(p[w], dp[w], dot);
+      }
+    }
+    float dq[DPL];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) dq[d] = 0.f;
+    const bool own = valid && i >= r0 && i < r1 && sc < n_qm;
+#pragma unroll
+    for (int w = 0; w < WMAX; ++w) {
+      if (w < W) {
+        const float ds = p[w] * (dp[w] - dot) / sq;
+        if (valid && lane8 == (w & 7)) {
+          tds[sc * WMAX + w] = ds;
+          tp[sc * WMAX + w] = pd[w];
+        }
+        float kf[DPL];
+        vload<T, DPL>(reinterpret_cast<const T*>(ldsK + imK.slot(idx[w]) * rs) + lane8 * DPL, kf);
+#pragma unroll
+        for (int d = 0; d < DPL; ++d) dq[d] = fmaf(ds, kf[d], dq[d]);
+      }
+    }
+    if (own) vstore<T, DPL>(dqkv + (tok0 + i) * ld + head * HD + lane8 * DPL, dq);
+  }
+  __syncthreads();
+
+  // ---- phase 2: per key row j: gather dK~, dV~ from the rows that reference it ----
+  {
+    const int j = r0 + qs;
+    const bool valid = j < r1;
+    float dk[DPL], dv[DPL];
+#pragma unroll
+    for (int d = 0; d < DPL; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+    auto add = [&](int i, int w) {
+      const int s = qslot_of(i);
+      const float ds = tds[s * WMAX + w], pw = tp[s * WMAX + w];
+      float qf[DPL], gf[DPL];
+      vload<T, DPL>(reinterpret_cast<const T*>(ldsQ + s * rs) + lane8 * DPL, qf);
+      vload<T, DPL>(reinterpret_cast<const T*>(ldsG + s * rs) + lane8 * DPL, gf);
+#pragma unroll
+      for (int d = 0; d < DPL; ++d) {
+        dk[d] = fmaf(ds, qf[d], dk[d]);
+        dv[d] = fmaf(pw, gf[d], dv[d]);
+      }
+    };
+    if (valid) {
+      for (int i = max(0, j - h); i <= min(L - 1, j + h); ++i) {       // band references
+        const int lo = max(0, i - h), n = min(L, i + h + 1) - lo, pad = W - n;
+        const int w = (lo == 0 || pad == 0) ? (j - lo) : pad + (j - lo);
+        add(i, w);
+      }
+      if (j == L - 1) {                                                 // END padding of rows with lo == 0
+        for (int i = 0; i <= min(h, L - 1); ++i) {
+          const int n = min(L, i + h + 1);
+          for (int w = n; w < W; ++w) add(i, w);
+        }
+      }
+      if (j == 0) {                                                     // FRONT padding of rows with lo > 0
+        for (int i = max(h + 1, L - h); i < L; ++i) {
+          const int lo = i - h, n = L - lo, pad = W - n;
+          for (int w = 0; w < pad; ++w) add(i, w);
+        }
+      }
+      vstore<T, DPL>(dqkv + (tok0 + j) * ld + D + head * HD + lane8 * DPL, dk);
+      vstore<T, DPL>(dqkv + (tok0 + j) * ld + 2 * D + head * HD + lane8 * DPL, dv);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// latent_proj fold
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void fold_fwd_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqkv,
+                                const float* __restrict__ wl, const float* __restrict__ bl, T* __restrict__ weff,
+                                float* __restrict__ weff_f32, float* __restrict__ beff, int D, int hd) {
+  // one thread per (row r of [3D], column c of [D+1]); column D is the bias
+  const long total = 3L * D * (D + 1);
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(t / (D + 1)), c = (int)(t % (D + 1));
+    float v;
+    if (r < D) {
+      v = (c < D) ? wqkv[(long)r * D + c] : bqkv[r];
+    } else {
+      const int i = r % hd, base = r - i;
+      float acc = 0.f;
+      if (c < D) {
+        for (int j = 0; j < hd; ++j) acc = fmaf(wl[i * hd + j], wqkv[(long)(base + j) * D + c], acc);
+      } else {
+        for (int j = 0; j < hd; ++j) acc = fmaf(wl[i * hd + j], bqkv[base + j], acc);
+        acc += bl[i];
+      }
+      v = acc;
+    }
+    if (c < D) {
+      weff[(long)r * D + c] = from_f32<T>(v);
+      if (weff_f32) weff_f32[(long)r * D + c] = v;
+    } else {
+      beff[r] = v;
+    }
+  }
+}
+
+__global__ void fold_bwd_w_kernel(const float* __restrict__ dweff, const float* __restrict__ dbeff,
+                                  const float* __restrict__ wl, float* __restrict__ dwqkv, float* __restrict__ dbqkv,
+                                  int D, int hd) {
+  const long total = 3L * D * (D + 1);
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(t / (D + 1)), c = (int)(t % (D + 1));
+    float v;
+    if (r < D) {
+      v = (c < D) ? dweff[(long)r * D + c] : dbeff[r];
+    } else {
+      const int j = r % hd, base = r - j;
+      float acc = 0.f;
+      if (c < D) {
+        for (int i = 0; i < hd; ++i) acc = fmaf(wl[i * hd + j], dweff[(long)(base + i) * D + c], acc);
+      } else {
+        for (int i = 0; i < hd; ++i) acc = fmaf(wl[i * hd + j], dbeff[base + i], acc);
+      }
+      v = acc;
+    }
+    if (c < D) dwqkv[(long)r * D + c] = v;
+    else dbqkv[r] = v;
+  }
+}
+
+// dWl[i][j] = sum_z ( dWeff_z[i,:] . Wqkv_z[j,:] + dbeff_z[i] * bqkv_z[j] ), dbl[i] = sum_z dbeff_z[i]
+// grid (hd, 2H): block (i, z) produces one partial row of dWl and adds it atomically.
+__global__ __launch_bounds__(256) void fold_bwd_l_kernel(const float* __restrict__ dweff,
+                                                         const float* __restrict__ dbeff,
+                                                         const float* __restrict__ wqkv,
+                                                         const float* __restrict__ bqkv, float* __restrict__ dwl,
+                                                         float* __restrict__ dbl, int D, int hd) {
+  extern __shared__ float sh[];       // dWeff row [D] + partials [4][hd]
+  float* rowbuf = sh;
+  float* part = sh + D;
+  const int i = blockIdx.x, z = blockIdx.y;
+  const long base = (long)D + (long)z * hd;      // first row of this (s,h) block
+  for (int c = threadIdx.x; c < D; c += 256) rowbuf[c] = dweff[(base + i) * D + c];
+  __syncthreads();
+  const int nq = 256 / hd > 0 ? 256 / hd : 1;    // column splits per j (hd <= 256)
+  const int j = threadIdx.x % hd, qd = threadIdx.x / hd;
+  float acc = 0.f;
+  if (qd < nq) {
+    const float* wr = wqkv + (base + j) * D;
+    for (int c = qd; c < D; c += nq) acc = fmaf(rowbuf[c], wr[c], acc);
+    if (qd == 0) acc = fmaf(dbeff[base + i], bqkv[base + j], acc);
+    part[qd * hd + j] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < hd) {
+    float s = 0.f;
+    for (int q = 0; q < nq; ++q) s += part[q * hd + threadIdx.x];
+    atomicAdd(dwl + (long)i * hd + threadIdx.x, s);
+  }
+  if (threadIdx.x == 0) atomicAdd(dbl + i, dbeff[base + i]);
+}
+
+template <typename T, int DPL, int WMAX>
+int launch_attn(bool bwd, const AttnArgs& a, hipStream_t st) {
+  constexpr int HD = 8 * DPL;
+  const int rs = row_stride_bytes(HD, sizeof(T));
+  const int h = a.W / 2;
+  if (!bwd) {
+    const int rows = (FWD_QPB + 2 * h) + 2;
+    const size_t lds = (size_t)2 * rows * rs;
+    auto k = mhla_fwd_kernel<T, DPL, WMAX>;
+    if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((a.L + FWD_QPB - 1) / FWD_QPB, a.H, a.B);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+  } else {
+    const int krows = (BWD_RB + 4 * h) + 2 * (2 * h + 1);
+    const size_t lds = (size_t)2 * krows * rs + (size_t)2 * 64 * rs + (size_t)2 * 64 * WMAX * 4;
+    if (lds > 160 * 1024) return FAVIT_ERR_UNSUPPORTED;
+    auto k = mhla_bwd_kernel<T, DPL, WMAX>;
+    if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid((a.L + BWD_RB - 1) / BWD_RB, a.H, a.B);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
+  }
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+template <typename T, int WMAX>
+int dispatch_dpl(bool bwd, const AttnArgs& a, hipStream_t st) {
+  switch (a.hd) {
+    case 16: return launch_attn<T, 2, WMAX>(bwd, a, st);
+    case 32: return launch_attn<T, 4, WMAX>(bwd, a, st);
+    case 64: return launch_attn<T, 8, WMAX>(bwd, a, st);
+    case 128: return launch_attn<T, 16, WMAX>(bwd, a, st);
+    default: return FAVIT_ERR_UNSUPPORTED;
+  }
+}
+
+int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uint8_t* mask, int B, int L, int H, int hd,
+               int W, int dtype, float p, uint64_t seed, void* stream) {
+  if (!qkv || !out || (bwd && !dout) || B <= 0 || L <= 0 || H <= 0 || hd <= 0) return FAVIT_ERR_INVALID;
+  if (W <= 0 || (W & 1) == 0) return FAVIT_ERR_INVALID;      // even windows crash the reference (mhla.py:83)
+  if (W > 15) return FAVIT_ERR_UNSUPPORTED;
+  if (p < 0.f || p >= 1.f) return FAVIT_ERR_INVALID;
+  AttnArgs a;
+  a.qkv = qkv; a.dout = dout; a.out = out; a.mask = mask;
+  a.B = B; a.L = L; a.H = H; a.hd = hd; a.W = W;
+  a.inv_sqrt_hd = 0.f;
+  a.thresh = dropout_threshold(p);
+  a.keep_scale = 1.0f / (1.0f - p);
+  a.seed = seed;
+  hipStream_t st = as_stream(stream);
+  if (dtype == FAVIT_F32) return W <= 7 ? dispatch_dpl<float, 7>(bwd, a, st) : dispatch_dpl<float, 15>(bwd, a, st);
+  if (dtype == FAVIT_BF16) return W <= 7 ? dispatch_dpl<bf16_t, 7>(bwd, a, st) : dispatch_dpl<bf16_t, 15>(bwd, a, st);
+  return FAVIT_ERR_INVALID;
+}
+
+}  // namespace
+
+extern "C" int favit_mhla_attn_fwd(const void* qkv, void* out, const uint8_t* mask, int32_t B, int32_t L, int32_t H,
+                                   int32_t hd, int32_t W, int dtype, float dropout_p, uint64_t seed, void* stream) {
+  return attn_entry(false, qkv, nullptr, out, mask, B, L, H, hd, W, dtype, dropout_p, seed, stream);
+}
+
+extern "C" int favit_mhla_attn_bwd(const void* qkv, const void* dout, void* dqkv, const uint8_t* mask, int32_t B,
+                                   int32_t L, int32_t H, int32_t hd, int32_t W, int dtype, float dropout_p,
+                                   uint64_t seed, void* stream) {
+  return attn_entry(true, qkv, dout, dqkv, mask, B, L, H, hd, W, dtype, dropout_p, seed, stream);
+}
+
+extern "C" int favit_mhla_fold_fwd(const float* wqkv, const float* bqkv, const float* wl, const float* bl, void* weff,
+                                   int weff_dtype, float* weff_f32, float* beff, int32_t D, int32_t H, void* stream) {
+  if (!wqkv || !bqkv || !wl || !bl || !weff || !beff || D <= 0 || H <= 0 || D % H) return FAVIT_ERR_INVALID;
+  const int hd = D / H;
+  const long total = 3L * D * (D + 1);
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipStream_t st = as_stream(stream);
+  if (weff_dtype == FAVIT_F32)
+    hipLaunchKernelGGL((fold_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, wqkv, bqkv, wl, bl, (float*)weff, weff_f32, beff, D, hd);
+  else if (weff_dtype == FAVIT_BF16)
+    hipLaunchKernelGGL((fold_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, wqkv, bqkv, wl, bl, (bf16_t*)weff, weff_f32, beff, D, hd);
+  else
+    return FAVIT_ERR_INVALID;
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const float* wqkv, const float* bqkv,
+                                   const float* wl, float* dwqkv, float* dbqkv, float* dwl, float* dbl, int32_t D,
+                                   int32_t H, void* stream) {
+  if (!dweff || !dbeff || !wqkv || !bqkv || !wl || !dwqkv || !dbqkv || !dwl || !dbl || D <= 0 || H <= 0 || D % H)
+    return FAVIT_ERR_INVALID;
+  const int hd = D / H;
+  if (hd > 256) return FAVIT_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  const long total = 3L * D * (D + 1);
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(fold_bwd_w_kernel, dim3(grid), dim3(256), 0, st, dweff, dbeff, wl, dwqkv, dbqkv, D, hd);
+  FAVIT_CHECK_LAUNCH();
+  (void)hipMemsetAsync(dwl, 0, sizeof(float) * hd * hd, st);
+  (void)hipMemsetAsync(dbl, 0, sizeof(float) * hd, st);
+  const int nq = 256 / hd > 0 ? 256 / hd : 1;
+  const size_t lds = sizeof(float) * ((size_t)D + (size_t)nq * hd);
+  hipLaunchKernelGGL(fold_bwd_l_kernel, dim3(hd, 2 * H), dim3(256), lds, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D, hd);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}

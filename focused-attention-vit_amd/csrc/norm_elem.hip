@@ -1,0 +1,485 @@
+// HBM-bound row / elementwise kernels of the encoder path (gfx950):
+// LayerNorm fwd/bwd, row reduction, cast, dropout, patchify, CLS/pos prologue,
+// cross-entropy and AdamW.  All are one-pass, 16-B-per-lane coalesced; LayerNorm keeps
+// the row in registers (one 64-lane wave per token row, shuffle reductions).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// LayerNorm: one wave per row, NV float4 chunks per lane (D <= 256*NV)
+// ---------------------------------------------------------------------------------
+template <typename OutT>
+__device__ __forceinline__ void store4(OutT* p, float a, float b, float c, float d) {
+  if constexpr (sizeof(OutT) == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+  } else {
+    bf16x4 o = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+    *reinterpret_cast<bf16x4*>(p) = o;
+  }
+}
+template <typename InT>
+__device__ __forceinline__ float4 load4(const InT* p) {
+  if constexpr (sizeof(InT) == 4) {
+    return *reinterpret_cast<const float4*>(p);
+  } else {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+  }
+}
+
+template <typename OutT, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, OutT* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                     int D, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  const int nchunk = D >> 2;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i4 = lane + 64 * c;
+    v[c] = (i4 < nchunk) ? *reinterpret_cast<const float4*>(xr + 4 * i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i4 = lane + 64 * c;
+    if (i4 < nchunk) {
+      const float a = v[c].x - mu, b = v[c].y - mu, cc = v[c].z - mu, d = v[c].w - mu;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+  OutT* yr = y + row * (long)D;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i4 = lane + 64 * c;
+    if (i4 < nchunk) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * i4);
+      const float4 b = *reinterpret_cast<const float4*>(beta + 4 * i4);
+      store4<OutT>(yr + 4 * i4, (v[c].x - mu) * rs * g.x + b.x, (v[c].y - mu) * rs * g.y + b.y,
+                   (v[c].z - mu) * rs * g.z + b.z, (v[c].w - mu) * rs * g.w + b.w);
+    }
+  }
+}
+
+template <typename DyT, typename LpT, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy, const float* __restrict__ x, long ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ dres, float* __restrict__ dx,
+                                                     long lddx, LpT* __restrict__ dx_lp,
+                                                     float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
+                                                     long rows, int D) {
+  __shared__ float red[4][2][256 * NV > 2048 ? 2048 : 256 * NV];   // [wave][gamma|beta][D padded]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = D >> 2;
+  float4 gam[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i4 = lane + 64 * c;
+    gam[c] = (i4 < nchunk) ? *reinterpret_cast<const float4*>(gamma + 4 * i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ag[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float invD = 1.0f / (float)D;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    const float* xr = x + row * ldx;
+    const DyT* dyr = dy + row * (long)D;
+    float4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const int i4 = lane + 64 * c;
+      if (i4 < nchunk) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * i4);
+        const float4 d = load4<DyT>(dyr + 4 * i4);
+        xh[c] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        g[c] = make_float4(d.x * gam[c].x, d.y * gam[c].y, d.z * gam[c].z, d.w * gam[c].w);
+        s1 += (g[c].x + g[c].y) + (g[c].z + g[c].w);
+        s2 += (g[c].x * xh[c].x + g[c].y * xh[c].y) + (g[c].z * xh[c].z + g[c].w * xh[c].w);
+        ag[c].x += d.x * xh[c].x; ag[c].y += d.y * xh[c].y; ag[c].z += d.z * xh[c].z; ag[c].w += d.w * xh[c].w;
+        ab[c].x += d.x; ab[c].y += d.y; ab[c].z += d.z; ab[c].w += d.w;
+      } else {
+        xh[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        g[c] = xh[c];
+      }
+    }
+    const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const int i4 = lane + 64 * c;
+      if (i4 < nchunk) {
+        float o0 = rs * (g[c].x - c1 - xh[c].x * c2), o1 = rs * (g[c].y - c1 - xh[c].y * c2);
+        float o2 = rs * (g[c].z - c1 - xh[c].z * c2), o3 = rs * (g[c].w - c1 - xh[c].w * c2);
+        if (dres) {
+          const float4 r = *reinterpret_cast<const float4*>(dres + row * lddx + 4 * i4);
+          o0 += r.x; o1 += r.y; o2 += r.z; o3 += r.w;
+        }
+        *reinterpret_cast<float4*>(dx + row * lddx + 4 * i4) = make_float4(o0, o1, o2, o3);
+        if (dx_lp) store4<LpT>(dx_lp + row * (long)D + 4 * i4, o0, o1, o2, o3);
+      }
+    }
+  }
+  // fold the 4 waves of the workgroup, then one partial row per workgroup
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i4 = lane + 64 * c;
+    if (i4 < nchunk) {
+      *reinterpret_cast<float4*>(&red[wave][0][4 * i4]) = ag[c];
+      *reinterpret_cast<float4*>(&red[wave][1][4 * i4]) = ab[c];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) {
+    dgamma_part[(long)blockIdx.x * D + i] = (red[0][0][i] + red[1][0][i]) + (red[2][0][i] + red[3][0][i]);
+    dbeta_part[(long)blockIdx.x * D + i] = (red[0][1][i] + red[1][1][i]) + (red[2][1][i] + red[3][1][i]);
+  }
+}
+
+__global__ void reduce_rows_kernel(const float* __restrict__ in, long ld, float* __restrict__ out, long rows, int cols,
+                                   int accumulate) {
+  // block = 64 columns x 4 row groups
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  float s = 0.f;
+  if (col < cols)
+    for (long r = ry; r < rows; r += 4) s += in[r * ld + col];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < cols) {
+    const float t = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+    out[col] = accumulate ? out[col] + t : t;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+template <typename S, typename T>
+__global__ void cast_kernel(const S* __restrict__ src, T* __restrict__ dst, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = load4<S>(src + 4 * i);
+    store4<T>(dst + 4 * i, v.x, v.y, v.z, v.w);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dst[i] = from_f32<T>(to_f32(src[i]));
+}
+
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n, uint32_t thresh, float scale,
+                               uint64_t seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = favit_keep(seed, (uint64_t)i, thresh) ? from_f32<T>(to_f32(x[i]) * scale) : from_f32<T>(0.f);
+}
+
+// ---------------------------------------------------------------------------------
+// patchify: 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)'  (models/vit.py:38-39)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void patchify_fwd_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int C, int HW, int P) {
+  const int g = HW / P;
+  const long K = (long)P * P * C;
+  const long total = (long)B * g * g * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / K;
+    const int e = (int)(i - row * K);
+    const int c = e % C, pp = e / C, p2 = pp % P, p1 = pp / P;
+    const int b = (int)(row / (g * g)), pr = (int)(row % (g * g)), ph = pr / g, pw = pr % g;
+    out[i] = from_f32<T>(img[(((long)b * C + c) * HW + (ph * P + p1)) * HW + pw * P + p2]);
+  }
+}
+
+__global__ void patchify_bwd_kernel(const float* __restrict__ dpatch, float* __restrict__ dimg, int B, int C, int HW,
+                                    int P) {
+  const int g = HW / P;
+  const long K = (long)P * P * C;
+  const long total = (long)B * C * HW * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % HW), yy = (int)((i / HW) % HW), c = (int)((i / ((long)HW * HW)) % C);
+    const int b = (int)(i / ((long)HW * HW * C));
+    const int ph = yy / P, p1 = yy % P, pw = xx / P, p2 = xx % P;
+    dimg[i] = dpatch[((long)b * g * g + ph * g + pw) * K + (p1 * P + p2) * C + c];
+  }
+}
+
+// x[b,0,:] = cls + pos[0]; x[b,1+n,:] = tok[b,n,:] + pos[1+n]   (models/vit.py:292-296)
+__global__ void embed_prologue_fwd_kernel(const float* __restrict__ tok, const float* __restrict__ cls,
+                                          const float* __restrict__ pos, float* __restrict__ x, int B, int N, int D) {
+  const int d4n = D >> 2;
+  const long total = (long)B * (N + 1) * d4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d4 = (int)(i % d4n);
+    const long r = i / d4n;
+    const int l = (int)(r % (N + 1));
+    const long b = r / (N + 1);
+    float4 v = (l == 0) ? *reinterpret_cast<const float4*>(cls + 4 * d4)
+                        : *reinterpret_cast<const float4*>(tok + ((b * N + (l - 1)) * (long)D) + 4 * d4);
+    if (pos) {
+      const float4 p = *reinterpret_cast<const float4*>(pos + (long)l * D + 4 * d4);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    *reinterpret_cast<float4*>(x + r * (long)D + 4 * d4) = v;
+  }
+}
+
+// dtok = dx[:,1:], dcls = sum_b dx[b,0], dpos[l] = sum_b dx[b,l]
+template <typename T>
+__global__ void embed_prologue_bwd_kernel(const float* __restrict__ dx, T* __restrict__ dtok, float* __restrict__ dcls,
+                                          float* __restrict__ dpos, int B, int N, int D) {
+  const long LD = (long)(N + 1) * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < LD; i += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(i / D), d = (int)(i % D);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float v = dx[(long)b * LD + i];
+      s += v;
+      if (l > 0 && dtok) dtok[((long)b * N + (l - 1)) * D + d] = from_f32<T>(v);
+    }
+    if (dpos) dpos[i] = s;
+    if (l == 0 && dcls) dcls[d] = s;
+  }
+}
+
+// mean cross-entropy rows: loss_rows[b] = lse - logit[label]; dlogits = (softmax - onehot) * grad_scale
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits,
+                                                            const int64_t* __restrict__ labels,
+                                                            float* __restrict__ loss_rows, float* __restrict__ dlogits,
+                                                            int B, int C, float grad_scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= B) return;
+  const float* lr = logits + (long)row * C;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, lr[c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += __expf(lr[c] - m);
+  s = wave_sum(s);
+  const float lse = m + __logf(s);
+  const int lab = (int)labels[row];
+  if (lane == 0) loss_rows[row] = lse - lr[lab];
+  if (dlogits) {
+    const float inv = 1.0f / s;
+    for (int c = lane; c < C; c += 64)
+      dlogits[(long)row * C + c] = (__expf(lr[c] - m) * inv - (c == lab ? 1.f : 0.f)) * grad_scale;
+  }
+}
+
+// torch.optim.AdamW semantics (decoupled weight decay), one flat fp32 chunk
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2, float gscale) {
+  const float step = lr / bc1, rbc2 = rsqrtf(bc2);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.0f - lr * wd);
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    pi -= step * mi / (sqrtf(vi) * rbc2 + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+inline int grid_for(long n, int block = 256, int cap = 4096) {
+  long g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+#define LN_DISPATCH_NV(D, MACRO)            \
+  do {                                      \
+    const int nv__ = ((D) + 255) / 256;     \
+    if (nv__ <= 1) { MACRO(1); }            \
+    else if (nv__ <= 2) { MACRO(2); }       \
+    else if (nv__ <= 3) { MACRO(3); }       \
+    else if (nv__ <= 4) { MACRO(4); }       \
+    else if (nv__ <= 8) { MACRO(8); }       \
+    else return FAVIT_ERR_UNSUPPORTED;      \
+  } while (0)
+
+extern "C" int favit_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                                   int y_dtype, float* mean, float* rstd, int64_t rows, int32_t D, float eps,
+                                   void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || D <= 0) return FAVIT_ERR_INVALID;
+  if ((D & 3) || (ldx & 3)) return FAVIT_ERR_ALIGN;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define LN_FWD(NV)                                                                                              \
+  if (y_dtype == FAVIT_F32)                                                                                     \
+    hipLaunchKernelGGL((ln_fwd_kernel<float, NV>), grid, dim3(256), 0, st, x, (long)ldx, gamma, beta, (float*)y, \
+                       mean, rstd, (long)rows, D, eps);                                                         \
+  else                                                                                                          \
+    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NV>), grid, dim3(256), 0, st, x, (long)ldx, gamma, beta,          \
+                       (bf16_t*)y, mean, rstd, (long)rows, D, eps)
+  LN_DISPATCH_NV(D, LN_FWD);
+#undef LN_FWD
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x, int64_t ldx, const float* gamma,
+                                   const float* mean, const float* rstd, const float* dres, float* dx, int64_t lddx,
+                                   void* dx_lp, int lp_dtype, float* dgamma_part, float* dbeta_part, int32_t nparts,
+                                   int64_t rows, int32_t D, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_part || !dbeta_part || rows <= 0 || D <= 0 ||
+      nparts <= 0)
+    return FAVIT_ERR_INVALID;
+  if ((D & 3) || (ldx & 3) || (lddx & 3)) return FAVIT_ERR_ALIGN;
+  if (dy_dtype != lp_dtype && dx_lp) return FAVIT_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((unsigned)nparts);
+#define LN_BWD(NV)                                                                                                 \
+  if (dy_dtype == FAVIT_F32)                                                                                       \
+    hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, dim3(256), 0, st, (const float*)dy, x, (long)ldx,  \
+                       gamma, mean, rstd, dres, dx, (long)lddx, (float*)dx_lp, dgamma_part, dbeta_part, (long)rows, \
+                       D);                                                                                         \
+  else                                                                                                             \
+    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t, NV>), grid, dim3(256), 0, st, (const bf16_t*)dy, x,          \
+                       (long)ldx, gamma, mean, rstd, dres, dx, (long)lddx, (bf16_t*)dx_lp, dgamma_part,            \
+                       dbeta_part, (long)rows, D)
+  LN_DISPATCH_NV(D, LN_BWD);
+#undef LN_BWD
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_t rows, int32_t cols,
+                                 int32_t accumulate, void* stream) {
+  if (!in || !out || rows <= 0 || cols <= 0) return FAVIT_ERR_INVALID;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 63) / 64), dim3(256), 0, as_stream(stream), in, (long)ld, out,
+                     (long)rows, cols, accumulate);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+  if (!src || !dst || n < 0) return FAVIT_ERR_INVALID;
+  if (n == 0) return FAVIT_OK;
+  if ((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 7)) return FAVIT_ERR_ALIGN;
+  hipStream_t st = as_stream(stream);
+  const int g = grid_for((n + 3) / 4);
+  if (src_dtype == FAVIT_F32 && dst_dtype == FAVIT_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, (long)n);
+  else if (src_dtype == FAVIT_BF16 && dst_dtype == FAVIT_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, (long)n);
+  else if (src_dtype == FAVIT_F32 && dst_dtype == FAVIT_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, (long)n);
+  else if (src_dtype == FAVIT_BF16 && dst_dtype == FAVIT_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, (long)n);
+  else
+    return FAVIT_ERR_INVALID;
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, void* stream) {
+  if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return FAVIT_ERR_INVALID;
+  if (n == 0) return FAVIT_OK;
+  hipStream_t st = as_stream(stream);
+  const uint32_t th = dropout_threshold(p);
+  const float scale = 1.0f / (1.0f - p);
+  if (dtype == FAVIT_F32)
+    hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (float*)y, (long)n, th, scale, seed);
+  else if (dtype == FAVIT_BF16)
+    hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (long)n, th, scale, seed);
+  else
+    return FAVIT_ERR_INVALID;
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_patchify_fwd(const float* img, void* out, int out_dtype, int32_t B, int32_t C, int32_t HW,
+                                  int32_t P, void* stream) {
+  if (!img || !out || B <= 0 || C <= 0 || HW <= 0 || P <= 0 || HW % P) return FAVIT_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  const long total = (long)B * C * HW * HW;
+  if (out_dtype == FAVIT_F32)
+    hipLaunchKernelGGL((patchify_fwd_kernel<float>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, img, (float*)out, B, C, HW, P);
+  else if (out_dtype == FAVIT_BF16)
+    hipLaunchKernelGGL((patchify_fwd_kernel<bf16_t>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, img, (bf16_t*)out, B, C, HW, P);
+  else
+    return FAVIT_ERR_INVALID;
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_patchify_bwd(const float* dpatch, float* dimg, int32_t B, int32_t C, int32_t HW, int32_t P,
+                                  void* stream) {
+  if (!dpatch || !dimg || B <= 0 || C <= 0 || HW <= 0 || P <= 0 || HW % P) return FAVIT_ERR_INVALID;
+  const long total = (long)B * C * HW * HW;
+  hipLaunchKernelGGL(patchify_bwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(stream), dpatch, dimg, B, C, HW, P);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_embed_prologue_fwd(const float* tok, const float* cls, const float* pos, float* x, int32_t B,
+                                        int32_t N, int32_t D, void* stream) {
+  if (!tok || !cls || !x || B <= 0 || N <= 0 || D <= 0) return FAVIT_ERR_INVALID;
+  if (D & 3) return FAVIT_ERR_ALIGN;
+  const long total = (long)B * (N + 1) * (D / 4);
+  hipLaunchKernelGGL(embed_prologue_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), tok, cls, pos, x, B, N, D);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_embed_prologue_bwd(const float* dx, void* dtok, int dtok_dtype, float* dcls, float* dpos,
+                                        int32_t B, int32_t N, int32_t D, void* stream) {
+  if (!dx || B <= 0 || N <= 0 || D <= 0) return FAVIT_ERR_INVALID;
+  const long total = (long)(N + 1) * D;
+  hipStream_t st = as_stream(stream);
+  if (dtok_dtype == FAVIT_F32)
+    hipLaunchKernelGGL((embed_prologue_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, dx, (float*)dtok, dcls, dpos, B, N, D);
+  else if (dtok_dtype == FAVIT_BF16)
+    hipLaunchKernelGGL((embed_prologue_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, st, dx, (bf16_t*)dtok, dcls, dpos, B, N, D);
+  else
+    return FAVIT_ERR_INVALID;
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_cross_entropy(const float* logits, const int64_t* labels, float* loss_rows, float* dlogits,
+                                   int32_t B, int32_t C, float grad_scale, void* stream) {
+  if (!logits || !labels || !loss_rows || B <= 0 || C <= 0) return FAVIT_ERR_INVALID;
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), logits, labels, loss_rows, dlogits, B, C, grad_scale);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, float bias_c1, float bias_c2, float grad_scale,
+                           void* stream) {
+  if (!p || !g || !m || !v || n < 0) return FAVIT_ERR_INVALID;
+  if (n == 0) return FAVIT_OK;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, grad_scale);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_abi_version(void) { return FAVIT_ABI_VERSION; }
+
+extern "C" const char* favit_strerror(int code) {
+  switch (code) {
+    case FAVIT_OK: return "ok";
+    case FAVIT_ERR_INVALID: return "invalid argument";
+    case FAVIT_ERR_UNSUPPORTED: return "unsupported shape/dtype combination";
+    case FAVIT_ERR_ALIGN: return "pointer or leading-dimension alignment requirement violated";
+    case FAVIT_ERR_LAUNCH: return "HIP kernel launch failed";
+    default: return "unknown favit error";
+  }
+}

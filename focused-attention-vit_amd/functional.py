@@ -1,0 +1,642 @@
+"""Forward/backward chains of the encoder hot path, built on the HIP kernels.
+
+Each ``*Op`` below restates one reference forward (cited per class) as a sequence of
+libfavit kernel launches and supplies the hand-written backward sequence.  ``OpFn`` is
+the single ``torch.autograd.Function`` that plugs an Op into autograd so that the
+``nn.Module`` mirrors in ``models/`` stay drop-in (``loss.backward()`` works unchanged).
+
+Data layout in HBM: the residual stream is fp32 ``[B*L, D]``; every GEMM
+operand is a contiguous row-major ``[rows, features]`` matrix in the compute dtype (bf16
+or fp32); q, k~, v~ live interleaved in one ``[B*L, 3D]`` buffer exactly as the fused qkv
+projection writes them; gradients of the residual stream are kept in fp32 plus a
+compute-dtype copy that feeds the backward GEMMs.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import kernels as K
+from ._abi import ACT_DGELU, ACT_GELU, ACT_NONE
+
+# ------------------------------------------------------------------------------------
+# configuration
+# ------------------------------------------------------------------------------------
+_STATE = {"cdt": torch.float32, "epoch": 0}
+
+
+def set_compute_dtype(d) -> None:
+    """'fp32' (exact f32 MFMA path, the parity mode) or 'bf16' (bf16 MFMA, fp32 accumulate)."""
+    if isinstance(d, str):
+        d = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[d]
+    if d not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be fp32 or bf16")
+    _STATE["cdt"] = d
+
+
+def get_compute_dtype() -> torch.dtype:
+    return _STATE["cdt"]
+
+
+def bump_weight_epoch() -> None:
+    """Called by optimizers that update parameters through raw pointers."""
+    _STATE["epoch"] += 1
+
+
+_WCACHE = {}
+
+
+def wcast(w: torch.Tensor) -> torch.Tensor:
+    """Parameter in the compute dtype (cached per (storage, version, epoch))."""
+    cdt = _STATE["cdt"]
+    w = w.detach()
+    if w.dtype == cdt and w.is_contiguous():
+        return w
+    key = (w.data_ptr(), tuple(w.shape))
+    tag = (w._version, _STATE["epoch"], cdt)
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    c = K.cast(w, cdt)
+    _WCACHE[key] = (tag, c)
+    return c
+
+
+def _seed() -> int:
+    # drawn from torch's CPU generator: reproducible under torch.manual_seed, no device sync
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+def _as_cdt(x: torch.Tensor) -> torch.Tensor:
+    cdt = _STATE["cdt"]
+    x = x.contiguous()
+    return x if x.dtype == cdt else K.cast(x, cdt)
+
+
+def _as_f32(x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous()
+    return x if x.dtype == torch.float32 else K.cast(x, torch.float32)
+
+
+def _mask_u8(mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if mask is None:
+        return None
+    return (mask != 0).to(torch.uint8).contiguous()
+
+
+# ------------------------------------------------------------------------------------
+# GEMM helpers (nn.Linear forward / backward)
+# ------------------------------------------------------------------------------------
+def lin_fwd(a, w_c, bias, M, N, Kd, out_dtype, *, act=ACT_NONE, residual=None, want_pre=False, drop=(0.0, 0)):
+    out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    pre = torch.empty((M, N), dtype=out_dtype, device=a.device) if want_pre else None
+    K.gemm(a, w_c, out, M, N, Kd, Kd, Kd, N, bias=bias, act=act, aux_out=pre, ld_aux_out=N, residual=residual,
+           ld_res=N, dropout_p=drop[0], dropout_seed=drop[1])
+    return (out, pre) if want_pre else out
+
+
+def lin_bwd_x(dy, w_c, M, N, Kd, out_dtype, *, dgelu_pre=None, drop=(0.0, 0)):
+    """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(pre) * dropout-mask)."""
+    dx = torch.empty((M, Kd), dtype=out_dtype, device=dy.device)
+    K.gemm(dy, w_c, dx, M, Kd, N, N, Kd, Kd, b_kmajor=False, act=ACT_DGELU if dgelu_pre is not None else ACT_NONE,
+           aux_in=dgelu_pre, ld_aux_in=Kd, dropout_p=drop[0], dropout_seed=drop[1])
+    return dx
+
+
+def lin_bwd_w(dy, a, M, N, Kd, want_bias=True):
+    """dw[N,K] = dy[M,N]^T @ a[M,K] (fp32, split-K over the tokens), db[N] = column sums of dy (fused)."""
+    dw = torch.empty((N, Kd), dtype=torch.float32, device=dy.device)
+    db = torch.zeros(N, dtype=torch.float32, device=dy.device) if want_bias else None
+    K.gemm(dy, a, dw, N, Kd, M, N, Kd, Kd, a_kmajor=False, b_kmajor=False, a_rowsum=db)
+    return dw, db
+
+
+# ------------------------------------------------------------------------------------
+# scaled-dot-product attention on the MFMA GEMM (dense variants)
+# ------------------------------------------------------------------------------------
+class _View:
+    """[rows, ld] matrix holding per-(batch, head) [L, hd] blocks: element (b,h,l,d) at
+    off + b*sb + h*sh + l*ld + d."""
+    __slots__ = ("t", "off", "ld", "sb", "sh")
+
+    def __init__(self, t, off, ld, sb, sh):
+        self.t, self.off, self.ld, self.sb, self.sh = t, off, ld, sb, sh
+
+
+def sdpa_fwd(q: _View, k: _View, v: _View, o: _View, B, H, Lq, Lk, hd, scale, mask, m_sb, m_sq, p, seed):
+    cdt = q.t.dtype
+    Z = B * H
+    S = torch.empty((Z, Lq, Lk), dtype=torch.float32, device=q.t.device)
+    K.gemm(q.t, k.t, S, Lq, Lk, hd, q.ld, k.ld, Lk, alpha=scale, batch=Z, batch_inner=H, sA=(q.sb, q.sh),
+           sB=(k.sb, k.sh), sC=(H * Lq * Lk, Lq * Lk), a_off=q.off, b_off=k.off)
+    P, Pd = K.softmax_fwd(S, cdt, H, Z, Lq, Lk, mask, m_sb, m_sq, p, seed)
+    K.gemm(Pd, v.t, o.t, Lq, hd, Lk, Lk, v.ld, o.ld, b_kmajor=False, batch=Z, batch_inner=H,
+           sA=(H * Lq * Lk, Lq * Lk), sB=(v.sb, v.sh), sC=(o.sb, o.sh), b_off=v.off, c_off=o.off)
+    return P, Pd
+
+
+def sdpa_bwd(q: _View, k: _View, v: _View, do: _View, dq: _View, dk: _View, dv: _View, P, Pd, B, H, Lq, Lk, hd,
+             scale, p, seed):
+    Z = B * H
+    sP = (H * Lq * Lk, Lq * Lk)
+    dPd = torch.empty((Z, Lq, Lk), dtype=torch.float32, device=q.t.device)
+    K.gemm(do.t, v.t, dPd, Lq, Lk, hd, do.ld, v.ld, Lk, batch=Z, batch_inner=H, sA=(do.sb, do.sh), sB=(v.sb, v.sh),
+           sC=sP, a_off=do.off, b_off=v.off)
+    dS = K.softmax_bwd(P, dPd, Z, Lq, Lk, p, seed)
+    # dQ = scale * dS . K
+    K.gemm(dS, k.t, dq.t, Lq, hd, Lk, Lk, k.ld, dq.ld, b_kmajor=False, alpha=scale, batch=Z, batch_inner=H, sA=sP,
+           sB=(k.sb, k.sh), sC=(dq.sb, dq.sh), b_off=k.off, c_off=dq.off)
+    # dK = scale * dS^T . Q
+    K.gemm(dS, q.t, dk.t, Lk, hd, Lq, Lk, q.ld, dk.ld, a_kmajor=False, b_kmajor=False, alpha=scale, batch=Z,
+           batch_inner=H, sA=sP, sB=(q.sb, q.sh), sC=(dk.sb, dk.sh), b_off=q.off, c_off=dk.off)
+    # dV = Pd^T . dO
+    K.gemm(Pd, do.t, dv.t, Lk, hd, Lq, Lk, do.ld, dv.ld, a_kmajor=False, b_kmajor=False, batch=Z, batch_inner=H,
+           sA=sP, sB=(do.sb, do.sh), sC=(dv.sb, dv.sh), b_off=do.off, c_off=dv.off)
+
+
+# ------------------------------------------------------------------------------------
+# attention chains: input = LayerNorm output xn [M, D] (compute dtype), output fp32 [M, D]
+# (+ residual fused into the projection epilogue).  bwd takes the compute-dtype copy of the
+# output gradient and returns (dxn [M,D] compute dtype, [param grads in `names` order]).
+# ------------------------------------------------------------------------------------
+class MHLAChain:
+    """MultiHeadLatentAttention.forward (models/mhla.py:85-161)."""
+    names = ("qkv.weight", "qkv.bias", "latent_proj.weight", "latent_proj.bias", "proj.weight", "proj.bias")
+
+    def __init__(self, H, W, p_attn=0.0, p_proj=0.0):
+        if W % 2 == 0:
+            raise ValueError("window_size must be odd: the reference crashes on even sizes (models/mhla.py:83)")
+        self.H, self.W, self.p_attn, self.p_proj = H, W, p_attn, p_proj
+
+    def fwd(self, xn, prm, B, L, residual, mask, training):
+        wqkv, bqkv, wl, bl, wp, bp = prm
+        M, D = xn.shape
+        H, hd = self.H, D // self.H
+        pa = self.p_attn if training else 0.0
+        pp = self.p_proj if training else 0.0
+        sa = _seed() if pa > 0 else 0
+        sp = _seed() if pp > 0 else 0
+        weff, beff = K.mhla_fold_fwd(wqkv.detach(), bqkv.detach(), wl.detach(), bl.detach(), H, xn.dtype)
+        qkv = lin_fwd(xn, weff, beff, M, 3 * D, D, xn.dtype)
+        o = K.mhla_attn_fwd(qkv, B, L, H, hd, self.W, mask, pa, sa)
+        wp_c = wcast(wp)
+        y = lin_fwd(o, wp_c, bp.detach(), M, D, D, torch.float32, residual=residual, drop=(pp, sp))
+        return y, (xn, weff, qkv, o, wp_c, mask, B, L, pa, sa, pp, sp, prm)
+
+    def bwd(self, saved, dy_lp):
+        xn, weff, qkv, o, wp_c, mask, B, L, pa, sa, pp, sp, prm = saved
+        wqkv, bqkv, wl, bl, wp, bp = prm
+        M, D = xn.shape
+        H, hd = self.H, D // self.H
+        dym = K.dropout(dy_lp, pp, sp) if pp > 0 else dy_lp
+        do = lin_bwd_x(dym, wp_c, M, D, D, xn.dtype)
+        dwp, dbp = lin_bwd_w(dym, o, M, D, D)
+        dqkv = K.mhla_attn_bwd(qkv, do, B, L, H, hd, self.W, mask, pa, sa)
+        dxn = lin_bwd_x(dqkv, weff, M, 3 * D, D, xn.dtype)
+        dweff, dbeff = lin_bwd_w(dqkv, xn, M, 3 * D, D)
+        dwqkv, dbqkv, dwl, dbl = K.mhla_fold_bwd(dweff, dbeff, wqkv.detach(), bqkv.detach(), wl.detach(), H)
+        return dxn, [dwqkv, dbqkv, dwl, dbl, dwp, dbp]
+
+
+class DenseChain:
+    """vit.MultiHeadAttention.forward (models/vit.py:77-104) and, with the
+    nn.MultiheadAttention parameter names, the use_mhla=False branch
+    (models/vit_mhla.py:57-62,96-101).  mask: key-keep [B,L] (torch MHA) or None."""
+
+    def __init__(self, H, p_attn=0.0, p_proj=0.0, torch_mha=False):
+        self.H, self.p_attn, self.p_proj, self.torch_mha = H, p_attn, p_proj, torch_mha
+        self.names = (("in_proj_weight", "in_proj_bias", "out_proj.weight", "out_proj.bias") if torch_mha
+                      else ("qkv.weight", "qkv.bias", "proj.weight", "proj.bias"))
+
+    def _views(self, t, B, L, D, hd):
+        ld = 3 * D
+        return (_View(t, 0, ld, L * ld, hd), _View(t, D, ld, L * ld, hd), _View(t, 2 * D, ld, L * ld, hd))
+
+    def fwd(self, xn, prm, B, L, residual, mask, training):
+        wqkv, bqkv, wp, bp = prm
+        M, D = xn.shape
+        H, hd = self.H, D // self.H
+        pa = self.p_attn if training else 0.0
+        pp = self.p_proj if (training and not self.torch_mha) else 0.0   # nn.MultiheadAttention has no proj dropout
+        sa = _seed() if pa > 0 else 0
+        sp = _seed() if pp > 0 else 0
+        wqkv_c, wp_c = wcast(wqkv), wcast(wp)
+        qkv = lin_fwd(xn, wqkv_c, bqkv.detach(), M, 3 * D, D, xn.dtype)
+        o = torch.empty((M, D), dtype=xn.dtype, device=xn.device)
+        q, k, v = self._views(qkv, B, L, D, hd)
+        ov = _View(o, 0, D, L * D, hd)
+        P, Pd = sdpa_fwd(q, k, v, ov, B, H, L, L, hd, hd ** -0.5, mask, L if mask is not None else 0, 0, pa, sa)
+        y = lin_fwd(o, wp_c, bp.detach(), M, D, D, torch.float32, residual=residual, drop=(pp, sp))
+        return y, (xn, wqkv_c, qkv, o, wp_c, P, Pd, B, L, pa, sa, pp, sp)
+
+    def bwd(self, saved, dy_lp):
+        xn, wqkv_c, qkv, o, wp_c, P, Pd, B, L, pa, sa, pp, sp = saved
+        M, D = xn.shape
+        H, hd = self.H, D // self.H
+        dym = K.dropout(dy_lp, pp, sp) if pp > 0 else dy_lp
+        do = lin_bwd_x(dym, wp_c, M, D, D, xn.dtype)
+        dwp, dbp = lin_bwd_w(dym, o, M, D, D)
+        dqkv = torch.empty_like(qkv)
+        q, k, v = self._views(qkv, B, L, D, hd)
+        dq, dk, dv = self._views(dqkv, B, L, D, hd)
+        sdpa_bwd(q, k, v, _View(do, 0, D, L * D, hd), dq, dk, dv, P, Pd, B, H, L, L, hd, hd ** -0.5, pa, sa)
+        dxn = lin_bwd_x(dqkv, wqkv_c, M, 3 * D, D, xn.dtype)
+        dwqkv, dbqkv = lin_bwd_w(dqkv, xn, M, 3 * D, D)
+        return dxn, [dwqkv, dbqkv, dwp, dbp]
+
+
+class CrossChain:
+    """CrossAttention.forward (models/attention.py:37-78; ONE head, scores / embed_dim**0.5,
+    no dropout after out_proj) and MultiHeadCrossAttention.forward (attention.py:105-148)."""
+    names = ("q_proj.weight", "q_proj.bias", "k_proj.weight", "k_proj.bias", "v_proj.weight", "v_proj.bias",
+             "out_proj.weight", "out_proj.bias")
+
+    def __init__(self, H, p_attn=0.0):
+        self.H, self.p_attn = H, p_attn
+
+    def fwd(self, qn, kn, prm, B, Lq, Lk, residual, mask, training):
+        wq, bq, wk, bk, wv, bv, wo, bo = prm
+        D = qn.shape[1]
+        H, hd = self.H, D // self.H
+        pa = self.p_attn if training else 0.0
+        sa = _seed() if pa > 0 else 0
+        cdt = qn.dtype
+        wq_c, wk_c, wv_c, wo_c = wcast(wq), wcast(wk), wcast(wv), wcast(wo)
+        q = lin_fwd(qn, wq_c, bq.detach(), B * Lq, D, D, cdt)
+        k = lin_fwd(kn, wk_c, bk.detach(), B * Lk, D, D, cdt)
+        v = lin_fwd(kn, wv_c, bv.detach(), B * Lk, D, D, cdt)
+        o = torch.empty((B * Lq, D), dtype=cdt, device=qn.device)
+        scale = 1.0 / (hd ** 0.5)
+        P, Pd = sdpa_fwd(_View(q, 0, D, Lq * D, hd), _View(k, 0, D, Lk * D, hd), _View(v, 0, D, Lk * D, hd),
+                         _View(o, 0, D, Lq * D, hd), B, H, Lq, Lk, hd, scale, mask,
+                         Lq * Lk if mask is not None else 0, Lk if mask is not None else 0, pa, sa)
+        y = lin_fwd(o, wo_c, bo.detach(), B * Lq, D, D, torch.float32, residual=residual)
+        return y, (qn, kn, q, k, v, o, (wq_c, wk_c, wv_c, wo_c), P, Pd, B, Lq, Lk, pa, sa, scale)
+
+    def bwd(self, saved, dy_lp):
+        qn, kn, q, k, v, o, (wq_c, wk_c, wv_c, wo_c), P, Pd, B, Lq, Lk, pa, sa, scale = saved
+        D = qn.shape[1]
+        H, hd = self.H, D // self.H
+        cdt = qn.dtype
+        Mq, Mk = B * Lq, B * Lk
+        do = lin_bwd_x(dy_lp, wo_c, Mq, D, D, cdt)
+        dwo, dbo = lin_bwd_w(dy_lp, o, Mq, D, D)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        sdpa_bwd(_View(q, 0, D, Lq * D, hd), _View(k, 0, D, Lk * D, hd), _View(v, 0, D, Lk * D, hd),
+                 _View(do, 0, D, Lq * D, hd), _View(dq, 0, D, Lq * D, hd), _View(dk, 0, D, Lk * D, hd),
+                 _View(dv, 0, D, Lk * D, hd), P, Pd, B, H, Lq, Lk, hd, scale, pa, sa)
+        dqn = lin_bwd_x(dq, wq_c, Mq, D, D, cdt)
+        dwq, dbq = lin_bwd_w(dq, qn, Mq, D, D)
+        dkn = torch.empty((Mk, D), dtype=torch.float32, device=qn.device)
+        K.gemm(dk, wk_c, dkn, Mk, D, D, D, D, D, b_kmajor=False)
+        K.gemm(dv, wv_c, dkn, Mk, D, D, D, D, D, b_kmajor=False, accumulate=True)
+        dwk, dbk = lin_bwd_w(dk, kn, Mk, D, D)
+        dwv, dbv = lin_bwd_w(dv, kn, Mk, D, D)
+        return dqn, dkn, [dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo]
+
+
+class MLPChain:
+    """MLP.forward fc1 -> GELU -> drop -> fc2 -> drop (models/vit.py:124-139)."""
+
+    def __init__(self, p=0.0, fc1="fc1", fc2="fc2"):
+        self.p = p
+        self.names = (f"{fc1}.weight", f"{fc1}.bias", f"{fc2}.weight", f"{fc2}.bias")
+
+    def fwd(self, xn, prm, residual, training):
+        w1, b1, w2, b2 = prm
+        M, D = xn.shape
+        Hd = w1.shape[0]
+        Do = w2.shape[0]
+        p = self.p if training else 0.0
+        s1 = _seed() if p > 0 else 0
+        s2 = _seed() if p > 0 else 0
+        w1_c, w2_c = wcast(w1), wcast(w2)
+        h, pre = lin_fwd(xn, w1_c, b1.detach(), M, Hd, D, xn.dtype, act=ACT_GELU, want_pre=True, drop=(p, s1))
+        y = lin_fwd(h, w2_c, b2.detach(), M, Do, Hd, torch.float32, residual=residual, drop=(p, s2))
+        return y, (xn, pre, h, w1_c, w2_c, p, s1, s2)
+
+    def bwd(self, saved, dy_lp):
+        xn, pre, h, w1_c, w2_c, p, s1, s2 = saved
+        M, D = xn.shape
+        Hd, Do = w1_c.shape[0], w2_c.shape[0]
+        dym = K.dropout(dy_lp, p, s2) if p > 0 else dy_lp
+        dpre = lin_bwd_x(dym, w2_c, M, Do, Hd, xn.dtype, dgelu_pre=pre, drop=(p, s1))
+        dw2, db2 = lin_bwd_w(dym, h, M, Do, Hd)
+        dxn = lin_bwd_x(dpre, w1_c, M, Hd, D, xn.dtype)
+        dw1, db1 = lin_bwd_w(dpre, xn, M, Hd, D)
+        return dxn, [dw1, db1, dw2, db2]
+
+
+# ------------------------------------------------------------------------------------
+# Ops (autograd granularity)
+# ------------------------------------------------------------------------------------
+class OpFn(torch.autograd.Function):
+    """forward(op, n_in, *inputs, *params); the Op owns the kernel sequences."""
+
+    @staticmethod
+    def forward(ctx, op, n_in, *tensors):
+        K.require_gpu(*[t for t in tensors if t is not None])
+        ins, prm = tensors[:n_in], tensors[n_in:]
+        out, saved = op.fwd(ins, prm)
+        ctx.op, ctx.saved, ctx.n_in, ctx.n_prm = op, saved, n_in, len(prm)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        din, dprm = ctx.op.bwd(ctx.saved, _as_f32(dout), ctx.needs_input_grad[2:2 + ctx.n_in])
+        ctx.saved = None
+        return (None, None, *din, *dprm)
+
+
+def run(op, inputs: Sequence[torch.Tensor], params: Sequence[torch.Tensor]) -> torch.Tensor:
+    return OpFn.apply(op, len(inputs), *inputs, *params)
+
+
+class LinearOp:
+    """nn.Linear on fp32 activations (head, standalone projections)."""
+
+    def __init__(self, act=ACT_NONE):
+        self.act = act
+
+    def fwd(self, ins, prm):
+        (x,), (w, b) = ins, prm
+        shp = x.shape
+        a = _as_cdt(x.reshape(-1, shp[-1]))
+        w_c = wcast(w)
+        M, Kd, N = a.shape[0], a.shape[1], w.shape[0]
+        y = lin_fwd(a, w_c, None if b is None else b.detach(), M, N, Kd, torch.float32)
+        return y.reshape(*shp[:-1], N), (a, w_c, shp, b is not None)
+
+    def bwd(self, saved, dy, needs):
+        a, w_c, shp, has_b = saved
+        M, Kd, N = a.shape[0], a.shape[1], w_c.shape[0]
+        dy_c = _as_cdt(dy.reshape(M, N))
+        dx = lin_bwd_x(dy_c, w_c, M, N, Kd, torch.float32).reshape(shp) if needs[0] else None
+        dw, db = lin_bwd_w(dy_c, a, M, N, Kd, want_bias=has_b)
+        return [dx], [dw, db] if has_b else [dw]
+
+
+class PatchEmbedOp:
+    """PatchEmbedding.forward (models/vit.py:43-53): rearrange + Linear(P*P*C -> D)."""
+
+    def __init__(self, P):
+        self.P = P
+
+    def fwd(self, ins, prm):
+        (img,), (w, b) = ins, prm
+        B, Cc, HW, _ = img.shape
+        patches = K.patchify_fwd(_as_f32(img), self.P, get_compute_dtype())
+        M, Kd = patches.shape
+        D = w.shape[0]
+        w_c = wcast(w)
+        tok = lin_fwd(patches, w_c, b.detach(), M, D, Kd, torch.float32)
+        return tok.reshape(B, M // B, D), (patches, w_c, (B, Cc, HW))
+
+    def bwd(self, saved, dy, needs):
+        patches, w_c, (B, Cc, HW) = saved
+        M, Kd = patches.shape
+        D = w_c.shape[0]
+        dy_c = _as_cdt(dy.reshape(M, D))
+        dw, db = lin_bwd_w(dy_c, patches, M, D, Kd)
+        dimg = None
+        if needs[0]:
+            dpatch = lin_bwd_x(dy_c, w_c, M, D, Kd, torch.float32)
+            dimg = K.patchify_bwd(dpatch, B, Cc, HW, self.P)
+        return [dimg], [dw, db]
+
+
+class PrologueOp:
+    """cat(cls, tokens) (+ pos_embed) (models/vit.py:292-296, models/sppp_mhla.py:303-304)."""
+
+    def __init__(self, has_pos):
+        self.has_pos = has_pos
+
+    def fwd(self, ins, prm):
+        (tok,) = ins
+        cls = prm[0]
+        pos = prm[1] if self.has_pos else None
+        B, N, D = tok.shape
+        x = K.embed_prologue_fwd(_as_f32(tok), cls.detach().contiguous(), None if pos is None else pos.detach().contiguous(),
+                                 B, N, D)
+        return x, (B, N, D)
+
+    def bwd(self, saved, dy, needs):
+        B, N, D = saved
+        dtok, dcls, dpos = K.embed_prologue_bwd(dy, B, N, D, torch.float32, want_pos=self.has_pos)
+        out = [dcls.reshape(1, 1, D)]
+        if self.has_pos:
+            out.append(dpos.reshape(1, N + 1, D))
+        return [dtok.reshape(B, N, D)], out
+
+
+class BlockSpec:
+    """Static description of one pre-LN transformer block (models/vit.py:165-179,
+    models/vit_mhla.py:77-109, models/mhla.py:205-222)."""
+
+    def __init__(self, attn, mlp):
+        self.attn, self.mlp = attn, mlp
+        self.names = (("norm1.weight", "norm1.bias") + tuple("attn." + n for n in attn.names) +
+                      ("norm2.weight", "norm2.bias") + tuple("mlp." + n for n in mlp.names))
+        self.n = len(self.names)
+
+
+class EncoderOp:
+    """A stack of pre-LN blocks on the fp32 residual stream [B, L, D]:
+    x += attn(LN1(x)); x += mlp(LN2(x))."""
+
+    def __init__(self, blocks: List[BlockSpec], mask=None, training=False):
+        self.blocks, self.mask, self.training = blocks, mask, training
+
+    def fwd(self, ins, prm):
+        (x,) = ins
+        B, L, D = x.shape
+        M = B * L
+        cdt = get_compute_dtype()
+        x = _as_f32(x).reshape(M, D)
+        tapes = []
+        off = 0
+        for bs in self.blocks:
+            p = [t.detach() for t in prm[off:off + bs.n]]
+            off += bs.n
+            na = len(bs.attn.names)
+            g1, b1 = p[0], p[1]
+            pa = p[2:2 + na]
+            g2, b2 = p[2 + na], p[3 + na]
+            pm = p[4 + na:]
+            xn1, mu1, rs1 = K.layernorm_fwd(x, D, g1, b1, M, D, cdt)
+            x1, sa = bs.attn.fwd(xn1, pa, B, L, x, self.mask, self.training)
+            xn2, mu2, rs2 = K.layernorm_fwd(x1, D, g2, b2, M, D, cdt)
+            x2, sm = bs.mlp.fwd(xn2, pm, x1, self.training)
+            tapes.append((x, mu1, rs1, g1, sa, x1, mu2, rs2, g2, sm))
+            x = x2
+        return x.reshape(B, L, D), (tapes, B, L, D)
+
+    def bwd(self, saved, dy, needs):
+        tapes, B, L, D = saved
+        M = B * L
+        g = dy.reshape(M, D)
+        g_lp = _as_cdt(g)
+        grads = []
+        for bs, tp in zip(reversed(self.blocks), reversed(tapes)):
+            x, mu1, rs1, g1, sa, x1, mu2, rs2, g2, sm = tp
+            dxn2, gm = bs.mlp.bwd(sm, g_lp)
+            g, g_lp, dg2, db2 = K.layernorm_bwd(dxn2, x1, D, g2, mu2, rs2, M, D, dres=g, want_lp=True)
+            dxn1, ga = bs.attn.bwd(sa, g_lp)
+            g, g_lp, dg1, db1 = K.layernorm_bwd(dxn1, x, D, g1, mu1, rs1, M, D, dres=g, want_lp=True)
+            grads = [dg1, db1] + ga + [dg2, db2] + gm + grads
+        return [g.reshape(B, L, D)], grads
+
+
+class FinalNormOp:
+    """norm(x)[:, 0] (models/vit.py:303-307): only the CLS row of the last LayerNorm is computed."""
+
+    def fwd(self, ins, prm):
+        (x,), (g, b) = ins, prm
+        B, L, D = x.shape
+        x = _as_f32(x)
+        y, mu, rs = K.layernorm_fwd(x, L * D, g.detach(), b.detach(), B, D, torch.float32)
+        return y, (x, mu, rs, g.detach(), (B, L, D))
+
+    def bwd(self, saved, dy, needs):
+        x, mu, rs, g, (B, L, D) = saved
+        dx = torch.zeros((B, L, D), dtype=torch.float32, device=x.device)
+        _, _, dg, db = K.layernorm_bwd(dy, x, L * D, g, mu, rs, B, D, dx=dx, lddx=L * D)
+        return [dx], [dg, db]
+
+
+class AttnOp:
+    """Stand-alone attention module on fp32 [B, L, D] (no LayerNorm, no residual)."""
+
+    def __init__(self, chain, mask=None, training=False):
+        self.chain, self.mask, self.training = chain, mask, training
+
+    def fwd(self, ins, prm):
+        (x,) = ins
+        B, L, D = x.shape
+        xn = _as_cdt(x.reshape(B * L, D))
+        y, saved = self.chain.fwd(xn, list(prm), B, L, None, self.mask, self.training)
+        return y.reshape(B, L, D), (saved, (B, L, D))
+
+    def bwd(self, saved, dy, needs):
+        s, (B, L, D) = saved
+        dxn, grads = self.chain.bwd(s, _as_cdt(dy.reshape(B * L, D)))
+        return [_as_f32(dxn).reshape(B, L, D)], grads
+
+
+class MLPOp:
+    def __init__(self, chain, training=False):
+        self.chain, self.training = chain, training
+
+    def fwd(self, ins, prm):
+        (x,) = ins
+        shp = x.shape
+        xn = _as_cdt(x.reshape(-1, shp[-1]))
+        y, saved = self.chain.fwd(xn, list(prm), None, self.training)
+        return y.reshape(*shp[:-1], y.shape[-1]), (saved, shp)
+
+    def bwd(self, saved, dy, needs):
+        s, shp = saved
+        dxn, grads = self.chain.bwd(s, _as_cdt(dy.reshape(-1, dy.shape[-1])))
+        return [_as_f32(dxn).reshape(shp)], grads
+
+
+class CrossAttnOp:
+    """Stand-alone (MultiHead)CrossAttention on fp32 query [B,Lq,D], key_value [B,Lk,D]."""
+
+    def __init__(self, chain, mask=None, training=False):
+        self.chain, self.mask, self.training = chain, mask, training
+
+    def fwd(self, ins, prm):
+        q, kv = ins
+        B, Lq, D = q.shape
+        Lk = kv.shape[1]
+        qn, kn = _as_cdt(q.reshape(B * Lq, D)), _as_cdt(kv.reshape(B * Lk, D))
+        y, saved = self.chain.fwd(qn, kn, list(prm), B, Lq, Lk, None, self.mask, self.training)
+        return y.reshape(B, Lq, D), (saved, (B, Lq, Lk, D))
+
+    def bwd(self, saved, dy, needs):
+        s, (B, Lq, Lk, D) = saved
+        dqn, dkn, grads = self.chain.bwd(s, _as_cdt(dy.reshape(B * Lq, D)))
+        return [_as_f32(dqn).reshape(B, Lq, D), dkn.reshape(B, Lk, D)], grads
+
+
+class CrossBlockOp:
+    """CrossAttentionTransformerBlock.forward (models/attention.py:194-219)."""
+
+    def __init__(self, chain, mlp, mask=None, training=False):
+        self.chain, self.mlp, self.mask, self.training = chain, mlp, mask, training
+        self.names = (("norm1_query.weight", "norm1_query.bias", "norm1_kv.weight", "norm1_kv.bias") +
+                      tuple("attn." + n for n in chain.names) + ("norm2.weight", "norm2.bias") +
+                      tuple("mlp." + n for n in mlp.names))
+
+    def fwd(self, ins, prm):
+        q, kv = ins
+        B, Lq, D = q.shape
+        Lk = kv.shape[1]
+        Mq, Mk = B * Lq, B * Lk
+        cdt = get_compute_dtype()
+        p = [t.detach() for t in prm]
+        q2, kv2 = _as_f32(q).reshape(Mq, D), _as_f32(kv).reshape(Mk, D)
+        qn, muq, rsq = K.layernorm_fwd(q2, D, p[0], p[1], Mq, D, cdt)
+        kn, muk, rsk = K.layernorm_fwd(kv2, D, p[2], p[3], Mk, D, cdt)
+        x1, sa = self.chain.fwd(qn, kn, p[4:12], B, Lq, Lk, q2, self.mask, self.training)
+        xn2, mu2, rs2 = K.layernorm_fwd(x1, D, p[12], p[13], Mq, D, cdt)
+        x2, sm = self.mlp.fwd(xn2, p[14:], x1, self.training)
+        return x2.reshape(B, Lq, D), (q2, kv2, muq, rsq, muk, rsk, sa, x1, mu2, rs2, sm, p, (B, Lq, Lk, D))
+
+    def bwd(self, saved, dy, needs):
+        q2, kv2, muq, rsq, muk, rsk, sa, x1, mu2, rs2, sm, p, (B, Lq, Lk, D) = saved
+        Mq, Mk = B * Lq, B * Lk
+        g = dy.reshape(Mq, D)
+        dxn2, gm = self.mlp.bwd(sm, _as_cdt(g))
+        g, g_lp, dg2, db2 = K.layernorm_bwd(dxn2, x1, D, p[12], mu2, rs2, Mq, D, dres=g, want_lp=True)
+        dqn, dkn, ga = self.chain.bwd(sa, g_lp)
+        dq, _, dgq, dbq = K.layernorm_bwd(dqn, q2, D, p[0], muq, rsq, Mq, D, dres=g)
+        dkv, _, dgk, dbk = K.layernorm_bwd(dkn, kv2, D, p[2], muk, rsk, Mk, D)
+        return [dq.reshape(B, Lq, D), dkv.reshape(B, Lk, D)], [dgq, dbq, dgk, dbk] + ga + [dg2, db2] + gm
+
+
+class PoolOp:
+    """SuperpixelPooling.pool over a batch (models/sppp.py:192-223, models/sppp_mhla.py:286-300)."""
+
+    def __init__(self, kind, perm, offs, R):
+        self.kind, self.perm, self.offs, self.R = kind, perm, offs, R
+
+    def fwd(self, ins, prm):
+        (emb,) = ins
+        emb = _as_f32(emb)
+        out, argmax = K.sppp_pool_fwd(emb, self.perm, self.offs, self.kind, self.R)
+        return out, (emb, argmax)
+
+    def bwd(self, saved, dy, needs):
+        emb, argmax = saved
+        return [K.sppp_pool_bwd(dy, emb, self.perm, self.offs, argmax, self.kind, self.R)], []
+
+
+class PosEncOp:
+    """DynamicPositionalEncoding.forward, centroid branch (models/sppp.py:267-300)."""
+
+    def __init__(self, cent):
+        self.cent = cent
+
+    def fwd(self, ins, prm):
+        (x,) = ins
+        return K.sppp_posenc_fwd(_as_f32(x), self.cent), None
+
+    def bwd(self, saved, dy, needs):
+        return [dy], []
+
+
+class DropoutOp:
+    """nn.Dropout on an fp32 activation (embedding dropout, models/vit.py:297)."""
+
+    def __init__(self, p):
+        self.p = p
+
+    def fwd(self, ins, prm):
+        s = _seed()
+        return K.dropout(_as_f32(ins[0]), self.p, s), s
+
+    def bwd(self, saved, dy, needs):
+        return [K.dropout(dy, self.p, saved)], []

@@ -1,0 +1,297 @@
+"""Tensor-level wrappers over the C ABI (include/favit.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+function below hands raw device pointers to libfavit.so.  All tensors must live on a
+ROCm device; there is no CPU path (the oracle in ``oracle/`` is test infrastructure and
+is never imported from the product).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _abi
+from ._abi import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, GemmDesc
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if torch.is_tensor(t_or_dtype) else t_or_dtype
+    try:
+        return _DT[d]
+    except KeyError:
+        raise TypeError(f"favit kernels support float32 / bfloat16 only, got {d}") from None
+
+
+def require_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "focused-attention-vit_amd runs its hot path in HIP kernels on an MI355X; got a CPU tensor. "
+                "There is no CPU fallback (move the module and its inputs to the GPU).")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# --------------------------------------------------------------------------------------
+def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias=None, act=ACT_NONE,
+         aux_in=None, ld_aux_in=0, aux_out=None, ld_aux_out=0, residual=None, ld_res=0, a_rowsum=None,
+         accumulate=False, alpha=1.0, batch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), split_k=0,
+         a_off=0, b_off=0, c_off=0, dropout_p=0.0, dropout_seed=0):
+    """C[m,n] = epilogue(alpha * sum_k A[m,k] B[n,k]).  Offsets/strides are in elements."""
+    require_gpu(A, B, Cc)
+    if A.dtype != B.dtype:
+        raise TypeError("gemm operands must share a dtype")
+    d = GemmDesc()
+    ea, ec = A.element_size(), Cc.element_size()
+    d.A = A.data_ptr() + a_off * ea
+    d.B = B.data_ptr() + b_off * ea
+    d.C = Cc.data_ptr() + c_off * ec
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.aux_in = aux_in.data_ptr() if aux_in is not None else None
+    d.aux_out = aux_out.data_ptr() if aux_out is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.a_rowsum = a_rowsum.data_ptr() if a_rowsum is not None else None
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.ld_aux_in, d.ld_aux_out, d.ld_res = ld_aux_in, ld_aux_out, ld_res
+    d.sAo, d.sAi = sA
+    d.sBo, d.sBi = sB
+    d.sCo, d.sCi = sC
+    d.batch, d.batch_inner = batch, batch_inner
+    d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
+    d.in_dtype, d.out_dtype = dt(A), dt(Cc)
+    d.act = act
+    d.accumulate = int(accumulate)
+    d.split_k = split_k
+    d.alpha = alpha
+    d.dropout_p = dropout_p
+    d.dropout_seed = dropout_seed
+    if bias is not None and bias.dtype != torch.float32:
+        raise TypeError("bias must be fp32")
+    if residual is not None and residual.dtype != torch.float32:
+        raise TypeError("residual must be fp32")
+    _abi.check(_abi.lib().favit_gemm(C.byref(d), _st()), "favit_gemm")
+
+
+def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    require_gpu(src)
+    src = src.contiguous()
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _abi.check(_abi.lib().favit_cast(_p(src), dt(src), _p(out), dt(out), src.numel(), _st()), "favit_cast")
+    return out
+
+
+def layernorm_fwd(x, ldx, gamma, beta, rows, D, out_dtype, eps=1e-5):
+    """x: fp32 rows with stride ldx -> y [rows, D] (out_dtype), mean, rstd."""
+    require_gpu(x, gamma, beta)
+    y = torch.empty((rows, D), dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().favit_layernorm_fwd(_p(x), ldx, _p(gamma), _p(beta), _p(y), dt(y), _p(mean), _p(rstd),
+                                              rows, D, eps, _st()), "favit_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None, lddx=None, want_lp=False):
+    """Returns dx (fp32, row stride lddx), dx_lp (dy.dtype copy or None), dgamma, dbeta."""
+    require_gpu(dy, x)
+    dev = x.device
+    if dx is None:
+        dx = torch.empty((rows, D), dtype=torch.float32, device=dev)
+        lddx = D
+    dx_lp = torch.empty((rows, D), dtype=dy.dtype, device=dev) if want_lp else None
+    nparts = int(min(512, (rows + 3) // 4))
+    part = torch.empty((2, nparts, D), dtype=torch.float32, device=dev)
+    _abi.check(_abi.lib().favit_layernorm_bwd(_p(dy), dt(dy), _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres),
+                                              _p(dx), lddx, _p(dx_lp), dt(dy), _p(part[0]), _p(part[1]), nparts,
+                                              rows, D, _st()), "favit_layernorm_bwd")
+    dgb = torch.empty((2, D), dtype=torch.float32, device=dev)
+    lib = _abi.lib()
+    _abi.check(lib.favit_reduce_rows(_p(part[0]), D, _p(dgb[0]), nparts, D, 0, _st()), "favit_reduce_rows")
+    _abi.check(lib.favit_reduce_rows(_p(part[1]), D, _p(dgb[1]), nparts, D, 0, _st()), "favit_reduce_rows")
+    return dx, dx_lp, dgb[0], dgb[1]
+
+
+def reduce_rows(t2d: torch.Tensor) -> torch.Tensor:
+    require_gpu(t2d)
+    rows, cols = t2d.shape
+    out = torch.empty(cols, dtype=torch.float32, device=t2d.device)
+    _abi.check(_abi.lib().favit_reduce_rows(_p(t2d), t2d.stride(0), _p(out), rows, cols, 0, _st()), "favit_reduce_rows")
+    return out
+
+
+def mhla_fold_fwd(wqkv, bqkv, wl, bl, H, dtype):
+    require_gpu(wqkv, bqkv, wl, bl)
+    D = wqkv.shape[1]
+    weff = torch.empty((3 * D, D), dtype=dtype, device=wqkv.device)
+    beff = torch.empty(3 * D, dtype=torch.float32, device=wqkv.device)
+    _abi.check(_abi.lib().favit_mhla_fold_fwd(_p(wqkv), _p(bqkv), _p(wl), _p(bl), _p(weff), dt(weff), None, _p(beff),
+                                              D, H, _st()), "favit_mhla_fold_fwd")
+    return weff, beff
+
+
+def mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H):
+    D = wqkv.shape[1]
+    hd = D // H
+    dev = wqkv.device
+    dwqkv = torch.empty_like(wqkv)
+    dbqkv = torch.empty_like(bqkv)
+    dwl = torch.empty((hd, hd), dtype=torch.float32, device=dev)
+    dbl = torch.empty(hd, dtype=torch.float32, device=dev)
+    _abi.check(_abi.lib().favit_mhla_fold_bwd(_p(dweff), _p(dbeff), _p(wqkv), _p(bqkv), _p(wl), _p(dwqkv), _p(dbqkv),
+                                              _p(dwl), _p(dbl), D, H, _st()), "favit_mhla_fold_bwd")
+    return dwqkv, dbqkv, dwl, dbl
+
+
+def mhla_attn_fwd(qkv, B, L, H, hd, W, mask=None, p=0.0, seed=0):
+    require_gpu(qkv, mask)
+    out = torch.empty((B * L, H * hd), dtype=qkv.dtype, device=qkv.device)
+    _abi.check(_abi.lib().favit_mhla_attn_fwd(_p(qkv), _p(out), _p(mask), B, L, H, hd, W, dt(qkv), p, seed, _st()),
+               "favit_mhla_attn_fwd")
+    return out
+
+
+def mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask=None, p=0.0, seed=0):
+    require_gpu(qkv, dout, mask)
+    dqkv = torch.empty_like(qkv)
+    _abi.check(_abi.lib().favit_mhla_attn_bwd(_p(qkv), _p(dout), _p(dqkv), _p(mask), B, L, H, hd, W, dt(qkv), p, seed,
+                                              _st()), "favit_mhla_attn_bwd")
+    return dqkv
+
+
+def softmax_fwd(S, p_dtype, H, Z, Lq, Lk, mask=None, m_sb=0, m_sq=0, p=0.0, seed=0):
+    require_gpu(S, mask)
+    P = torch.empty((Z, Lq, Lk), dtype=p_dtype, device=S.device)
+    Pd = torch.empty_like(P) if p > 0 else None
+    _abi.check(_abi.lib().favit_softmax_fwd(_p(S), _p(P), _p(Pd), dt(P), _p(mask), m_sb, m_sq, H, Z, Lq, Lk, p, seed,
+                                            _st()), "favit_softmax_fwd")
+    return P, (Pd if Pd is not None else P)
+
+
+def softmax_bwd(P, dPd, Z, Lq, Lk, p=0.0, seed=0):
+    dS = torch.empty_like(P)
+    _abi.check(_abi.lib().favit_softmax_bwd(_p(P), dt(P), _p(dPd), _p(dS), dt(dS), Z, Lq, Lk, p, seed, _st()),
+               "favit_softmax_bwd")
+    return dS
+
+
+def patchify_fwd(img, P, dtype):
+    require_gpu(img)
+    B, Cc, HW, HW2 = img.shape
+    if HW != HW2 or HW % P:
+        raise ValueError("patchify needs square images with size divisible by patch_size")
+    img = img.contiguous()
+    g = HW // P
+    out = torch.empty((B * g * g, P * P * Cc), dtype=dtype, device=img.device)
+    _abi.check(_abi.lib().favit_patchify_fwd(_p(img), _p(out), dt(out), B, Cc, HW, P, _st()), "favit_patchify_fwd")
+    return out
+
+
+def patchify_bwd(dpatch, B, Cc, HW, P):
+    dimg = torch.empty((B, Cc, HW, HW), dtype=torch.float32, device=dpatch.device)
+    _abi.check(_abi.lib().favit_patchify_bwd(_p(dpatch), _p(dimg), B, Cc, HW, P, _st()), "favit_patchify_bwd")
+    return dimg
+
+
+def embed_prologue_fwd(tok, cls, pos, B, N, D):
+    x = torch.empty((B, N + 1, D), dtype=torch.float32, device=tok.device)
+    _abi.check(_abi.lib().favit_embed_prologue_fwd(_p(tok), _p(cls), _p(pos), _p(x), B, N, D, _st()),
+               "favit_embed_prologue_fwd")
+    return x
+
+
+def embed_prologue_bwd(dx, B, N, D, tok_dtype, want_pos=True):
+    dev = dx.device
+    dtok = torch.empty((B * N, D), dtype=tok_dtype, device=dev)
+    dcls = torch.empty(D, dtype=torch.float32, device=dev)
+    dpos = torch.empty((N + 1, D), dtype=torch.float32, device=dev) if want_pos else None
+    _abi.check(_abi.lib().favit_embed_prologue_bwd(_p(dx), _p(dtok), dt(dtok), _p(dcls), _p(dpos), B, N, D, _st()),
+               "favit_embed_prologue_bwd")
+    return dtok, dcls, dpos
+
+
+def dropout(x, p, seed):
+    y = torch.empty_like(x)
+    _abi.check(_abi.lib().favit_dropout(_p(x), _p(y), dt(x), x.numel(), p, seed, _st()), "favit_dropout")
+    return y
+
+
+def sppp_map_patches(seg, P):
+    require_gpu(seg)
+    if seg.dtype != torch.int64:
+        seg = seg.to(torch.int64)
+    seg = seg.contiguous()
+    B, HW, _ = seg.shape
+    N = (HW // P) ** 2
+    dev = seg.device
+    rank = torch.empty((B, N), dtype=torch.int32, device=dev)
+    ntok = torch.empty(B, dtype=torch.int32, device=dev)
+    perm = torch.empty((B, N), dtype=torch.int32, device=dev)
+    offs = torch.empty((B, N + 1), dtype=torch.int32, device=dev)
+    dom = torch.empty((B, N), dtype=torch.int64, device=dev)
+    _abi.check(_abi.lib().favit_sppp_map_patches(_p(seg), _p(rank), _p(ntok), _p(perm), _p(offs), _p(dom), B, HW, P,
+                                                 _st()), "favit_sppp_map_patches")
+    return rank, ntok, perm, offs, dom
+
+
+def sppp_pool_fwd(emb, perm, offs, kind, R):
+    B, N, D = emb.shape
+    out = torch.empty((B, R, D), dtype=torch.float32, device=emb.device)
+    argmax = torch.empty((B, R, D), dtype=torch.int32, device=emb.device) if kind == 1 else None
+    _abi.check(_abi.lib().favit_sppp_pool_fwd(_p(emb), _p(perm), _p(offs), _p(out), _p(argmax), kind, B, N, R, D,
+                                              _st()), "favit_sppp_pool_fwd")
+    return out, argmax
+
+
+def sppp_pool_bwd(dout, emb, perm, offs, argmax, kind, R):
+    B, N, D = emb.shape
+    demb = torch.zeros_like(emb)
+    _abi.check(_abi.lib().favit_sppp_pool_bwd(_p(dout), _p(emb), None, _p(perm), _p(offs), _p(argmax), _p(demb), kind,
+                                              B, N, R, D, _st()), "favit_sppp_pool_bwd")
+    return demb
+
+
+def sppp_centroids(seg, S):
+    require_gpu(seg)
+    seg = seg.to(torch.int64).contiguous()
+    B, HW, _ = seg.shape
+    cent = torch.empty((B, S, 2), dtype=torch.float32, device=seg.device)
+    _abi.check(_abi.lib().favit_sppp_centroids(_p(seg), _p(cent), B, HW, S, _st()), "favit_sppp_centroids")
+    return cent
+
+
+def sppp_posenc_fwd(x, cent):
+    B, L, D = x.shape
+    y = torch.empty_like(x)
+    _abi.check(_abi.lib().favit_sppp_posenc_fwd(_p(x), _p(cent), _p(y), B, L, D, 0 if cent is None else cent.shape[1], _st()),
+               "favit_sppp_posenc_fwd")
+    return y
+
+
+def cross_entropy(logits, labels, grad_scale=None):
+    """Returns (loss_rows[B], dlogits or None)."""
+    require_gpu(logits, labels)
+    B, Cn = logits.shape
+    loss_rows = torch.empty(B, dtype=torch.float32, device=logits.device)
+    dlog = torch.empty_like(logits) if grad_scale is not None else None
+    _abi.check(_abi.lib().favit_cross_entropy(_p(logits), _p(labels), _p(loss_rows), _p(dlog), B, Cn,
+                                              0.0 if grad_scale is None else grad_scale, _st()), "favit_cross_entropy")
+    return loss_rows, dlog
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    _abi.check(_abi.lib().favit_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2,
+                                      grad_scale, _st()), "favit_adamw")

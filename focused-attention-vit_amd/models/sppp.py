@@ -1,0 +1,218 @@
+"""Mirror of the reference's models/sppp.py (SuperpixelSegmentation, PatchToSuperpixelMapper,
+SuperpixelPooling, DynamicPositionalEncoding, SPPPViT).
+
+The reference runs mapping / pooling / centroids as per-image, per-patch Python loops with a
+device sync per patch; here they are batched device kernels (csrc/sppp.hip).  The dict-based
+per-image API of the reference is kept (``map_patches`` returns the same ordered dict) and a
+batched device API is added for the model fast path.  SLIC itself (skimage, unpinned in the
+reference and absent from the image) is out of scope: ``SuperpixelSegmentation.segment`` calls
+skimage if it is importable, otherwise a label-map provider must be installed
+(``model.segmentation.set_label_maps(...)`` or assigning ``segment``)."""
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from ._backend import F, K, params
+from .vit import PatchEmbedding, TransformerBlock as _VitBlock, run_encoder
+
+
+class SuperpixelSegmentation:
+    """reference models/sppp.py:26-74"""
+
+    def __init__(self, num_segments: int = 16, compactness: float = 0.1, sigma: float = 1.0):
+        self.num_segments = num_segments
+        self.compactness = compactness
+        self.sigma = sigma
+        self._maps = None
+
+    def set_label_maps(self, maps: Optional[torch.Tensor]):
+        """Install precomputed label maps [B,H,W] (int64) returned by the next segment() calls."""
+        self._maps = maps
+
+    def segment(self, image: torch.Tensor) -> torch.Tensor:
+        if self._maps is not None:
+            maps = self._maps
+            return maps if image.dim() == 4 else maps[0]
+        try:
+            from skimage.segmentation import slic
+        except ImportError as e:
+            raise ImportError(
+                "SuperpixelSegmentation.segment needs scikit-image's SLIC (third-party CPU algorithm, not part "
+                "of the accelerated path). Install scikit-image or provide label maps via set_label_maps().") from e
+        batch_mode = image.dim() == 4
+        imgs = image if batch_mode else image[None]
+        out = []
+        for i in range(imgs.shape[0]):
+            img = imgs[i].permute(1, 2, 0).cpu().numpy()
+            seg = slic(img, n_segments=self.num_segments, compactness=self.compactness, sigma=self.sigma,
+                       start_label=0)
+            out.append(torch.from_numpy(seg).to(image.device))
+        return torch.stack(out) if batch_mode else out[0]
+
+
+class PatchToSuperpixelMapper:
+    """reference models/sppp.py:77-128"""
+
+    def __init__(self, patch_size: int):
+        self.patch_size = patch_size
+
+    def map_patches_batched(self, segmentation_maps: torch.Tensor):
+        """Device API: label maps [B,H,W] -> (patch_rank[B,N], n_tokens[B], perm[B,N], offs[B,N+1], dom[B,N])."""
+        return K.sppp_map_patches(segmentation_maps, self.patch_size)
+
+    def map_patches(self, segmentation_map: torch.Tensor, img_size: int) -> Dict[int, List[int]]:
+        """Reference API: ordered dict {dominant label: [patch idx]} in first-seen raster order."""
+        rank, ntok, perm, offs, dom = K.sppp_map_patches(segmentation_map[None], self.patch_size)
+        rank, dom = rank[0].tolist(), dom[0].tolist()
+        out: Dict[int, List[int]] = {}
+        order = sorted(set(rank))
+        keys = {}
+        for p, r in enumerate(rank):
+            keys.setdefault(r, dom[p])
+        for r in order:
+            out[int(keys[r])] = [p for p, rr in enumerate(rank) if rr == r]
+        return out
+
+
+class SuperpixelPooling:
+    """reference models/sppp.py:131-223"""
+
+    def __init__(self, pooling_type: str = 'mean'):
+        self.pooling_type = pooling_type
+
+    def _kind(self):
+        try:
+            return {"mean": 0, "max": 1, "attention": 2}[self.pooling_type]
+        except KeyError:
+            raise ValueError(f"Unsupported pooling type: {self.pooling_type}") from None
+
+    def pool_batched(self, patch_embeddings: torch.Tensor, perm, offs, R: int) -> torch.Tensor:
+        return F.run(F.PoolOp(self._kind(), perm, offs, R), [patch_embeddings], [])
+
+    def pool(self, patch_embeddings: torch.Tensor, superpixel_to_patches: Dict[int, List[int]]) -> torch.Tensor:
+        """Reference API ([N,D] or [B,N,D] embeddings + one mapping dict shared by the batch)."""
+        kind = self._kind()
+        squeeze = patch_embeddings.dim() == 2
+        emb = patch_embeddings[None] if squeeze else patch_embeddings
+        B, N, D = emb.shape
+        groups = list(superpixel_to_patches.values())
+        R = len(groups)
+        perm_l, offs_l = [], [0]
+        for g in groups:
+            perm_l += list(g)
+            offs_l.append(len(perm_l))
+        perm_l += [0] * (N - len(perm_l))
+        offs_l += [offs_l[-1]] * (N + 1 - len(offs_l))
+        dev = emb.device
+        perm = torch.tensor(perm_l, dtype=torch.int32, device=dev)[None].expand(B, N).contiguous()
+        offs = torch.tensor(offs_l, dtype=torch.int32, device=dev)[None].expand(B, N + 1).contiguous()
+        out = F.run(F.PoolOp(kind, perm, offs, R), [emb], [])
+        return out[0] if squeeze else out
+
+
+class DynamicPositionalEncoding(nn.Module):
+    """reference models/sppp.py:226-300"""
+
+    def __init__(self, embed_dim: int, dropout: float = 0.0):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x: torch.Tensor, superpixel_centroids: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if superpixel_centroids is not None:
+            L, n = x.shape[1], superpixel_centroids.shape[1]
+            if n != L and n != L - 1:
+                raise ValueError(f"centroids for {n} superpixels cannot be broadcast onto {L} tokens "
+                                 "(the reference fails here with a broadcast error, models/sppp.py:299)")
+            cent = superpixel_centroids.to(torch.float32).contiguous()
+        else:
+            cent = None
+        x = F.run(F.PosEncOp(cent), [x], [])
+        if self.training and self.dropout.p > 0:
+            x = F.run(F.DropoutOp(self.dropout.p), [x], [])
+        return x
+
+
+def sppp_tokens(model, x: torch.Tensor) -> torch.Tensor:
+    """Shared front end of the SPPP models (models/sppp_mhla.py:274-310): label maps -> patch
+    embedding -> device-side patch->superpixel mapping + pooling -> CLS -> centroid pos-enc."""
+    seg = model.segmentation.segment(x)
+    if seg.device != x.device:
+        seg = seg.to(x.device)
+    tok = model.patch_embed(x)
+    rank, ntok, perm, offs, _ = model.patch_mapper.map_patches_batched(seg)
+    R = getattr(model, "assume_num_tokens", None)
+    if R is None:
+        lo, hi = int(ntok.min().item()), int(ntok.max().item())      # one host sync; skip via assume_num_tokens
+        if lo != hi:
+            raise ValueError(f"images in the batch produced different superpixel-token counts ({lo}..{hi}); the "
+                             "reference fails here in torch.stack (models/sppp_mhla.py:300): bucket by count")
+        R = lo
+    pooled = model.pooling.pool_batched(tok, perm, offs, R)
+    t = F.run(F.PrologueOp(False), [pooled], [model.cls_token])
+    cent = K.sppp_centroids(seg, model.num_superpixels)
+    return model.pos_embed(t, cent)
+
+
+def calculate_superpixel_centroids(model, segmentation_maps: torch.Tensor) -> torch.Tensor:
+    return K.sppp_centroids(segmentation_maps, model.num_superpixels)
+
+
+class SPPPViT(nn.Module):
+    """reference models/sppp.py:303-520.  The reference constructor raises
+    (``VisionTransformer.TransformerBlock``, sppp.py:378); this keeps the signature and implements
+    the evident intent with vit.TransformerBlock."""
+
+    def __init__(self, img_size: int = 224, patch_size: int = 4, in_channels: int = 3, num_classes: int = 1000,
+                 embed_dim: int = 768, depth: int = 12, num_heads: int = 12, mlp_ratio: float = 4.0,
+                 dropout: float = 0.0, attn_dropout: float = 0.0, embed_dropout: float = 0.0,
+                 num_superpixels: int = 16, compactness: float = 0.1, pooling_type: str = 'mean'):
+        super().__init__()
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.embed_dim = embed_dim
+        self.depth = depth
+        self.num_heads = num_heads
+        self.num_superpixels = num_superpixels
+        self.segmentation = SuperpixelSegmentation(num_segments=num_superpixels, compactness=compactness)
+        self.patch_mapper = PatchToSuperpixelMapper(patch_size=patch_size)
+        self.pooling = SuperpixelPooling(pooling_type=pooling_type)
+        self.patch_embed = PatchEmbedding(img_size=img_size, patch_size=patch_size, in_channels=in_channels,
+                                          embed_dim=embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = DynamicPositionalEncoding(embed_dim, embed_dropout)
+        self.blocks = nn.ModuleList([
+            _VitBlock(embed_dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, dropout=dropout,
+                      attn_dropout=attn_dropout) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim)
+        self.head = nn.Linear(embed_dim, num_classes)
+        self._init_weights()
+
+    def _init_weights(self):
+        nn.init.normal_(self.cls_token, std=0.02)
+        self.apply(self._init_weights_recursive)
+
+    def _init_weights_recursive(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+
+    def _calculate_superpixel_centroids(self, segmentation_maps):
+        return calculate_superpixel_centroids(self, segmentation_maps)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        t = sppp_tokens(self, x)
+        t = run_encoder(self.blocks, t, None, self.training)
+        t = F.run(F.FinalNormOp(), [t], [self.norm.weight, self.norm.bias])
+        return F.run(F.LinearOp(), [t], [self.head.weight, self.head.bias])
+
+    def get_num_parameters(self) -> int:
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)

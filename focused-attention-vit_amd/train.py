@@ -1,0 +1,106 @@
+"""Training-step harness: the counterpart of the reference's hot loop
+(experiments/mhla_pretrained.py:350-372: zero_grad -> model(images) -> CrossEntropyLoss ->
+backward -> AdamW.step) with the name-based parameter groups of
+experiments/mhla_pretrained.py:308-327.  Loss and optimizer run in libfavit kernels
+(favit_cross_entropy, favit_adamw); nothing in the step synchronises with the host.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import functional as F
+from . import kernels as K
+from .dp import FlatBuffers, GradSync
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (mean reduction) forward + gradient in one kernel."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        B = logits.shape[0]
+        rows, dlog = K.cross_entropy(logits.contiguous(), labels.contiguous(), grad_scale=1.0 / B)
+        ctx.save_for_backward(dlog)
+        return K.reduce_rows(rows.view(B, 1))[0] / B
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        return dlog * g, None
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    return _CrossEntropyFn.apply(logits, labels)
+
+
+def param_groups(model: torch.nn.Module, lr: float, head_lr: Optional[float] = None,
+                 latent_lr_mult: float = 5.0) -> List[Dict]:
+    """The reference's name-based groups (experiments/mhla_pretrained.py:320-327): every
+    trainable parameter whose name contains 'latent_proj' trains at 5x lr, 'head' at head_lr."""
+    base, lat, head = [], [], []
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if "head" in n:
+            head.append(p)
+        elif "latent_proj" in n:
+            lat.append(p)
+        else:
+            base.append(p)
+    out = [{"params": base, "lr": lr}]
+    if lat:
+        out.append({"params": lat, "lr": lr * latent_lr_mult})
+    if head:
+        out.append({"params": head, "lr": head_lr if head_lr is not None else lr})
+    return [g for g in out if g["params"]]
+
+
+class FusedAdamW:
+    """torch.optim.AdamW semantics; one favit_adamw launch per parameter group over flat
+    parameter / gradient / moment buffers (and the DP all-reduce runs on the same flat
+    gradient buffers, see dp.py)."""
+
+    def __init__(self, groups, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, bucket_mb=32.0,
+                 distributed=None):
+        if isinstance(groups, torch.nn.Module):
+            groups = [{"params": list(groups.parameters())}]
+        elif groups and not isinstance(groups[0], dict):
+            groups = [{"params": list(groups)}]
+        self.groups = []
+        dist_on = torch.distributed.is_initialized() if distributed is None else distributed
+        for g in groups:
+            flat = FlatBuffers(g["params"])
+            self.groups.append({
+                "flat": flat, "lr": g.get("lr", lr), "betas": g.get("betas", betas), "eps": g.get("eps", eps),
+                "weight_decay": g.get("weight_decay", weight_decay),
+                "m": torch.zeros_like(flat.flat_p), "v": torch.zeros_like(flat.flat_p),
+                "sync": GradSync(flat, bucket_mb) if dist_on else None,
+            })
+        self.steps = 0
+        self.world = torch.distributed.get_world_size() if dist_on else 1
+
+    def zero_grad(self):
+        for g in self.groups:
+            g["flat"].zero_grad()
+
+    def step(self):
+        self.steps += 1
+        for g in self.groups:
+            if g["sync"] is not None:
+                g["sync"].finish(average=False)
+            f = g["flat"]
+            K.adamw(f.flat_p, f.flat_g, g["m"], g["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                    g["weight_decay"], self.steps, grad_scale=1.0 / self.world)
+        F.bump_weight_epoch()
+
+
+def train_step(model, images, labels, opt: FusedAdamW):
+    """One step of the reference's hot loop; returns the (device) loss tensor, no host sync."""
+    opt.zero_grad()
+    logits = model(images)
+    loss = cross_entropy(logits, labels)
+    loss.backward()
+    opt.step()
+    return loss

@@ -1,0 +1,211 @@
+/*
+ * favit.h -- C ABI of libfavit.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * focused-attention ViT encoder forward/backward hot path.
+ *
+ * The reference (zser092/Focused-Attention-ViT) has NO native/FFI layer: its hot path
+ * is the Python nn.Module surface of models/{vit,mhla,vit_mhla,sppp,sppp_mhla,attention}.py
+ * executing aten ops.  This header is the new boundary UNDER that surface: each entry
+ * point replaces the aten op sequence of the cited reference lines.  The host-side
+ * mirror of the reference classes (the models package of focused-attention-vit_amd) binds these
+ * with ctypes (focused-attention-vit_amd/_abi.py); INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer owned by the caller
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued asynchronously on it, nothing synchronises, nothing allocates
+ *   - return 0 on success, a negative FAVIT_ERR_* otherwise; never throws
+ *   - dtype codes: FAVIT_F32 (exact fp32 path, f32 MFMA) / FAVIT_BF16 (bf16 operands,
+ *     fp32 accumulation, bf16 MFMA)
+ *   - kernels are stateless and thread-compatible
+ */
+#ifndef FAVIT_H_
+#define FAVIT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FAVIT_ABI_VERSION 1
+
+enum { FAVIT_F32 = 0, FAVIT_BF16 = 1 };
+
+enum {
+  FAVIT_OK = 0,
+  FAVIT_ERR_INVALID = -1,     /* bad argument (null pointer, non-positive size, bad enum) */
+  FAVIT_ERR_UNSUPPORTED = -2, /* shape/dtype combination this build has no kernel for */
+  FAVIT_ERR_ALIGN = -3,       /* pointer / leading dimension alignment requirement violated */
+  FAVIT_ERR_LAUNCH = -4       /* hipLaunchKernel reported an error */
+};
+
+enum { FAVIT_ACT_NONE = 0, FAVIT_ACT_GELU = 1, FAVIT_ACT_DGELU = 2 };
+enum { FAVIT_POOL_MEAN = 0, FAVIT_POOL_MAX = 1, FAVIT_POOL_ATTENTION = 2 };
+
+int favit_abi_version(void);
+const char* favit_strerror(int code);
+
+/* ------------------------------------------------------------------------------------
+ * GEMM with fused epilogue: every nn.Linear on the path and the dense QK^T / attn.V
+ * contractions.   C[m,n] = epilogue( alpha * sum_k A[m,k] * B[n,k] )
+ *   replaces: aten::addmm / mm / bmm behind models/vit.py:40,72,74,95,100,119,121,252,
+ *             models/mhla.py:37,38, models/attention.py:30-33,63,75,131,144 and their
+ *             autograd backward (dX = dY.W, dW = dY^T.X, db = colsum dY).
+ * Operand layouts ("kmajor" = the contraction index is contiguous in memory):
+ *   a_kmajor=1: A[m*lda + k]   a_kmajor=0: A[k*lda + m]
+ *   b_kmajor=1: B[n*ldb + k]   b_kmajor=0: B[k*ldb + n]
+ *   forward  Y = X.W^T      : A=X (kmajor), B=W (kmajor)
+ *   dX = dY.W               : A=dY (kmajor), B=W with b_kmajor=0
+ *   dW = dY^T.X             : A=dY with a_kmajor=0, B=X with b_kmajor=0, K = tokens
+ * Epilogue order: v=alpha*acc; v+=bias[n]; aux_out=v; act; dropout; v+=residual; C (=|+=) v.
+ *   act=GELU: v=gelu_erf(v) (models/vit.py:135); act=DGELU: v*=gelu'(aux_in[m,n]).
+ *   dropout_p>0: v = keep(seed, m*N+n) ? v/(1-p) : 0  (nn.Dropout sites models/vit.py:102,
+ *   136,138, models/mhla.py:159; the same (seed,index) draw is reused by the backward GEMMs).
+ * accumulate=1 (or split_k>1) adds into C with fp32 atomics; C must then be FAVIT_F32.
+ * a_rowsum (a_kmajor=0 only): a_rowsum[m] += sum_k A[m,k]  (bias gradient, fused).
+ * Batched: z in [0,batch): ptr += (z / batch_inner) * s?o + (z % batch_inner) * s?i.
+ * ---------------------------------------------------------------------------------- */
+typedef struct favit_gemm_t {
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;     /* [N] fp32 or NULL */
+  const void* aux_in;    /* DGELU: pre-activation [M,N], dtype = in_dtype; else NULL */
+  void* aux_out;         /* optional copy of the pre-activation [M,N], dtype = out_dtype */
+  const float* residual; /* [M,N] fp32 or NULL */
+  float* a_rowsum;       /* [M] fp32 or NULL */
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc, ld_aux_in, ld_aux_out, ld_res;
+  int64_t sAo, sAi, sBo, sBi, sCo, sCi; /* batch strides in elements */
+  int32_t batch, batch_inner;
+  int32_t a_kmajor, b_kmajor;
+  int32_t in_dtype, out_dtype;
+  int32_t act;
+  int32_t accumulate;
+  int32_t split_k; /* 0 = library decides */
+  float alpha;
+  float dropout_p;
+  int32_t reserved_;
+  uint64_t dropout_seed;
+} favit_gemm_t;
+
+int favit_gemm(const favit_gemm_t* g, void* stream);
+
+/* dst[i] = (dst_dtype) src[i] */
+int favit_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (nn.LayerNorm, eps 1e-5, biased variance):
+ *   models/vit.py:155,157,251; models/vit_mhla.py:45,64,88,107,188,241.
+ * x is the fp32 residual stream with row stride ldx (lets the head normalise x[:,0]
+ * only); y has dtype y_dtype; mean/rstd [rows] are saved for backward.
+ * Backward: dx = LN'(dy) (+ dres if given); optional low-precision copy dx_lp; the
+ * affine gradients are produced as `nparts` partial sums [nparts, D] that
+ * favit_reduce_rows folds (deterministic, no atomics).
+ * ---------------------------------------------------------------------------------- */
+int favit_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int y_dtype,
+                        float* mean, float* rstd, int64_t rows, int32_t D, float eps, void* stream);
+int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x, int64_t ldx, const float* gamma,
+                        const float* mean, const float* rstd, const float* dres, float* dx, int64_t lddx,
+                        void* dx_lp, int lp_dtype, float* dgamma_part, float* dbeta_part, int32_t nparts,
+                        int64_t rows, int32_t D, void* stream);
+/* out[c] (+)= sum_r in[r*ld + c] */
+int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t accumulate,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * MHLA (models/mhla.py).  latent_proj (mhla.py:41,105-106) is one Linear(hd,hd) shared
+ * by K, V and all heads; it is folded algebraically into the qkv projection:
+ *   Weff[s,h] = Wl . Wqkv[s,h] , beff[s,h] = Wl . bqkv[s,h] + bl   for s in {k,v}
+ * so that one GEMM produces q, k~, v~.  fold_bwd maps the gradients of (Weff, beff)
+ * back to the real parameters qkv.{weight,bias} and latent_proj.{weight,bias}.
+ * ---------------------------------------------------------------------------------- */
+int favit_mhla_fold_fwd(const float* wqkv, const float* bqkv, const float* wl, const float* bl, void* weff,
+                        int weff_dtype, float* weff_f32 /* optional fp32 copy */, float* beff, int32_t D,
+                        int32_t H, void* stream);
+int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const float* wqkv, const float* bqkv,
+                        const float* wl, float* dwqkv, float* dbqkv, float* dwl, float* dbl, int32_t D, int32_t H,
+                        void* stream);
+
+/* Windowed attention core: window index rule (mhla.py:46-83, closed form in-kernel, the
+ * duplicated pad indices take part in the softmax), gather (117-126, never materialised),
+ * scores / sqrt(hd) (130-133), optional mask[B,L,L]!=0 keep (136-143), softmax + dropout
+ * (146-147), attn.V (151-154), head merge (157).  qkv is the [B*L, 3D] output of the folded
+ * projection (column = s*D + h*hd + d); out is [B*L, D] (column = h*hd + d).
+ * Backward recomputes the probabilities and writes dqkv [B*L, 3D]. */
+int favit_mhla_attn_fwd(const void* qkv, void* out, const uint8_t* mask, int32_t B, int32_t L, int32_t H,
+                        int32_t hd, int32_t W, int dtype, float dropout_p, uint64_t seed, void* stream);
+int favit_mhla_attn_bwd(const void* qkv, const void* dout, void* dqkv, const uint8_t* mask, int32_t B, int32_t L,
+                        int32_t H, int32_t hd, int32_t W, int dtype, float dropout_p, uint64_t seed,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Row softmax for the dense attention variants (models/vit.py:96, attention.py:71,140,
+ * nn.MultiheadAttention): S fp32 [Z, Lq, Lk] (already scaled by the GEMM alpha).
+ * mask (uint8, 0 = -inf) is addressed mask[(z / H) * m_sb + q * m_sq + k].
+ * P (dtype p_dtype) gets softmax(S); if dropout_p>0, Pd gets the dropped+rescaled P.
+ * Backward: dS = P * (dPd*keep/(1-p) - sum_k(...)) in ds_dtype.
+ * ---------------------------------------------------------------------------------- */
+int favit_softmax_fwd(const float* S, void* P, void* Pd, int p_dtype, const uint8_t* mask, int64_t m_sb,
+                      int64_t m_sq, int32_t H, int64_t Z, int32_t Lq, int32_t Lk, float dropout_p, uint64_t seed,
+                      void* stream);
+int favit_softmax_bwd(const void* P, int p_dtype, const float* dPd, void* dS, int ds_dtype, int64_t Z, int32_t Lq,
+                      int32_t Lk, float dropout_p, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Patch embedding front end.
+ * patchify: einops 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' (models/vit.py:38-39),
+ *   img fp32 NCHW -> rows [B*N, P*P*C] of out_dtype (channel fastest).
+ * embed_prologue: cat(cls, tokens) + pos_embed (models/vit.py:292-296,
+ *   models/vit_mhla.py:229-233); pos may be NULL (SPPP path adds its own encoding).
+ * ---------------------------------------------------------------------------------- */
+int favit_patchify_fwd(const float* img, void* out, int out_dtype, int32_t B, int32_t C, int32_t HW, int32_t P,
+                       void* stream);
+int favit_patchify_bwd(const float* dpatch, float* dimg, int32_t B, int32_t C, int32_t HW, int32_t P, void* stream);
+int favit_embed_prologue_fwd(const float* tok, const float* cls, const float* pos, float* x, int32_t B, int32_t N,
+                             int32_t D, void* stream);
+/* dtok (dtype dtok_dtype, [B*N, D], feeds the patch-embedding weight-gradient GEMM), dcls, dpos may be NULL */
+int favit_embed_prologue_bwd(const float* dx, void* dtok, int dtok_dtype, float* dcls, float* dpos, int32_t B,
+                             int32_t N, int32_t D, void* stream);
+
+/* Inverted dropout with a counter-based RNG (nn.Dropout sites, models/vit.py:136,138,
+ * 102, mhla.py:159); the mask is recomputed from (seed, index) in backward. */
+int favit_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * SPPP (models/sppp.py, models/sppp_mhla.py); the label map [B,HW,HW] int64 is an input.
+ * map_patches (sppp.py:91-128): dominant label per patch (max count, ties -> smallest
+ *   label), token rank = first-appearance order of the dominant labels in raster scan.
+ *   Outputs: patch_rank[B,N] int32, n_tokens[B] int32, perm[B,N] int32 (patches grouped
+ *   by rank, raster order inside), offs[B,N+1] int32 (group offsets into perm).
+ * pool (sppp.py:192-223): mean / max / 'attention' pooling of patch embeddings
+ *   emb[B,N,D] fp32 into tokens [B,R,D] fp32 (R = the common token count).
+ * centroids (sppp_mhla.py:226-262): per LABEL s<S mean (x/w, y/h), empty -> 0.5.
+ * posenc (sppp.py:267-300): x + [sin(cx*f), cos(cy*f)], CLS centroid (0.5,0.5)
+ *   prepended when n_cent < L; cent == NULL selects the index-sinusoid branch (sppp.py:257-266).
+ * ---------------------------------------------------------------------------------- */
+/* dom_ws: caller-provided workspace [B,N] int64, receives the dominant label of every patch */
+int favit_sppp_map_patches(const int64_t* seg, int32_t* patch_rank, int32_t* n_tokens, int32_t* perm,
+                           int32_t* offs, int64_t* dom_ws, int32_t B, int32_t HW, int32_t P, void* stream);
+int favit_sppp_pool_fwd(const float* emb, const int32_t* perm, const int32_t* offs, float* out, int32_t* argmax,
+                        int32_t kind, int32_t B, int32_t N, int32_t R, int32_t D, void* stream);
+int favit_sppp_pool_bwd(const float* dout, const float* emb, const int32_t* patch_rank, const int32_t* perm,
+                        const int32_t* offs, const int32_t* argmax, float* demb, int32_t kind, int32_t B,
+                        int32_t N, int32_t R, int32_t D, void* stream);
+int favit_sppp_centroids(const int64_t* seg, float* cent, int32_t B, int32_t HW, int32_t S, void* stream);
+int favit_sppp_posenc_fwd(const float* x, const float* cent, float* y, int32_t B, int32_t L, int32_t D,
+                          int32_t n_cent, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Harness-side pieces of the training step (experiments/mhla_pretrained.py:363-367):
+ * mean cross-entropy with its gradient, and a fused multi-tensor AdamW step.
+ * ---------------------------------------------------------------------------------- */
+int favit_cross_entropy(const float* logits, const int64_t* labels, float* loss_rows, float* dlogits, int32_t B,
+                        int32_t C, float grad_scale, void* stream);
+int favit_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                float eps, float weight_decay, float bias_c1, float bias_c2, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAVIT_H_ */

@@ -1,0 +1,316 @@
+"""GPU unit tests of the libfavit kernels through the C ABI (ctypes), each compared with a
+plain fp32 PyTorch restatement of the same op on the same seeded inputs.
+fp32 path: tolerance 2e-5 rel-L2 (exact-fp32 MFMA); bf16 path: inputs are rounded to bf16
+first, then 1e-2 (bf16 output rounding)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1e-2
+
+
+@pytest.fixture(scope="module")
+def K(favit):
+    return favit.kernels
+
+
+def _rand(shape, dtype, gen):
+    return torch.randn(shape, generator=gen, device=DEV, dtype=torch.float32).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,Kd", [(256, 384, 128), (130, 70, 50), (128, 128, 64), (1, 64, 64), (197, 1000, 384),
+                                    (64, 10, 192), (300, 200, 8)])
+def test_gemm_layouts(K, dtype, ak, bk, M, N, Kd):
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N * 3 + Kd)
+    A = _rand((M, Kd) if ak else (Kd, M), dtype, g)
+    B = _rand((N, Kd) if bk else (Kd, N), dtype, g)
+    C = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    K.gemm(A, B, C, M, N, Kd, A.stride(0), B.stride(0), N, a_kmajor=ak, b_kmajor=bk)
+    Af = A.float() if ak else A.float().t()
+    Bf = B.float() if bk else B.float().t()
+    ref = Af.double() @ Bf.double().t()
+    assert rel_l2(C, ref) < (2e-5 if dtype == torch.float32 else 2e-5), "fp32-accumulated product of exact inputs"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(K, favit, dtype):
+    from importlib import import_module
+    abi = favit._abi
+    g = torch.Generator(device=DEV).manual_seed(5)
+    M, N, Kd = 256, 384, 128
+    A, W = _rand((M, Kd), dtype, g), _rand((N, Kd), dtype, g)
+    bias = torch.randn(N, generator=g, device=DEV)
+    res = torch.randn((M, N), generator=g, device=DEV)
+    base = A.float() @ W.float().t() + bias
+    # bias + GELU with saved pre-activation
+    out = torch.empty((M, N), dtype=dtype, device=DEV)
+    pre = torch.empty_like(out)
+    K.gemm(A, W, out, M, N, Kd, Kd, Kd, N, bias=bias, act=abi.ACT_GELU, aux_out=pre, ld_aux_out=N)
+    assert rel_l2(pre.float(), base) < _tol(dtype)
+    assert rel_l2(out.float(), torch.nn.functional.gelu(base)) < _tol(dtype)
+    # bias + residual, fp32 out
+    out32 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    K.gemm(A, W, out32, M, N, Kd, Kd, Kd, N, bias=bias, residual=res, ld_res=N)
+    assert rel_l2(out32, base + res) < 2e-5
+    # dGELU epilogue:  (A W^T) * gelu'(pre)
+    prex = _rand((M, N), dtype, g)
+    K.gemm(A, W, out32, M, N, Kd, Kd, Kd, N, act=abi.ACT_DGELU, aux_in=prex, ld_aux_in=N)
+    x = prex.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert rel_l2(out32, (A.float() @ W.float().t()) * x.grad) < 2e-5
+    # accumulate (fp32 atomics) and alpha
+    acc = res.clone()
+    K.gemm(A, W, acc, M, N, Kd, Kd, Kd, N, accumulate=True, alpha=0.5)
+    assert rel_l2(acc, res + 0.5 * (A.float() @ W.float().t())) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_weight_grad_splitk_and_bias_grad(K, dtype):
+    """dW = dY^T X with the token dim as K (split-K + atomics) and the fused column sum."""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    T, N, Kd = 4133, 200, 136
+    dY, X = _rand((T, N), dtype, g), _rand((T, Kd), dtype, g)
+    dW = torch.empty((N, Kd), dtype=torch.float32, device=DEV)
+    db = torch.zeros(N, dtype=torch.float32, device=DEV)
+    K.gemm(dY, X, dW, N, Kd, T, N, Kd, Kd, a_kmajor=False, b_kmajor=False, a_rowsum=db)
+    assert rel_l2(dW, dY.double().t() @ X.double()) < 2e-5
+    assert rel_l2(db, dY.double().sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_batched_strided(K, dtype):
+    """Per-(batch, head) Q K^T out of an interleaved [B*L, 3D] qkv buffer."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    B, H, L, hd = 3, 4, 37, 16
+    D = H * hd
+    qkv = _rand((B * L, 3 * D), dtype, g)
+    S = torch.empty((B * H, L, L), dtype=torch.float32, device=DEV)
+    K.gemm(qkv, qkv, S, L, L, hd, 3 * D, 3 * D, L, alpha=0.25, batch=B * H, batch_inner=H, sA=(L * 3 * D, hd),
+           sB=(L * 3 * D, hd), sC=(H * L * L, L * L), a_off=0, b_off=D)
+    t = qkv.float().reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = 0.25 * (t[0] @ t[1].transpose(-2, -1)).reshape(B * H, L, L)
+    assert rel_l2(S, ref) < 2e-5
+
+
+def test_gemm_dropout_epilogue_matches_dropout_kernel(K):
+    g = torch.Generator(device=DEV).manual_seed(13)
+    M, N, Kd = 256, 128, 64
+    A, W = _rand((M, Kd), torch.float32, g), _rand((N, Kd), torch.float32, g)
+    y0 = torch.empty((M, N), device=DEV)
+    y1 = torch.empty((M, N), device=DEV)
+    K.gemm(A, W, y0, M, N, Kd, Kd, Kd, N)
+    K.gemm(A, W, y1, M, N, Kd, Kd, Kd, N, dropout_p=0.3, dropout_seed=1234)
+    ref = K.dropout(y0, 0.3, 1234)
+    assert torch.equal(y1 == 0, ref == 0)
+    assert rel_l2(y1, ref) < 1e-6
+    keep = (y1 != 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.02
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,D", [(37, 64), (500, 384), (9, 192), (33, 768), (5, 1536)])
+def test_layernorm_fwd_bwd(K, dtype, rows, D):
+    g = torch.Generator(device=DEV).manual_seed(rows + D)
+    x = torch.randn((rows, D), generator=g, device=DEV) * 2 + 0.5
+    gam = torch.randn(D, generator=g, device=DEV)
+    bet = torch.randn(D, generator=g, device=DEV)
+    y, mu, rs = K.layernorm_fwd(x, D, gam, bet, rows, D, dtype)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    assert rel_l2(y.float(), yr) < _tol(dtype)
+    dy = _rand((rows, D), dtype, g)
+    dres = torch.randn((rows, D), generator=g, device=DEV)
+    dx, dx_lp, dg, db = K.layernorm_bwd(dy, x, D, gam, mu, rs, rows, D, dres=dres, want_lp=True)
+    yr.backward(dy.float())
+    assert rel_l2(dx, xr.grad + dres) < 2e-5
+    assert rel_l2(dx_lp.float(), xr.grad + dres) < _tol(dtype)
+    assert rel_l2(dg, gr.grad) < 2e-5 and rel_l2(db, br.grad) < 2e-5
+
+
+def test_layernorm_strided_rows_for_cls_head(K):
+    B, L, D = 6, 17, 64
+    x = torch.randn(B, L, D, device=DEV)
+    gam, bet = torch.randn(D, device=DEV), torch.randn(D, device=DEV)
+    y, mu, rs = K.layernorm_fwd(x, L * D, gam, bet, B, D, torch.float32)
+    assert rel_l2(y, torch.nn.functional.layer_norm(x[:, 0], (D,), gam, bet)) < 2e-5
+
+
+def test_cast_roundtrip(K):
+    x = torch.randn(100003, device=DEV)
+    b = K.cast(x, torch.bfloat16)
+    assert torch.equal(b, x.to(torch.bfloat16))
+    assert torch.equal(K.cast(b, torch.float32), b.float())
+
+
+def test_patchify_matches_einops_order(K):
+    from oracle import favit_oracle as O
+    x = torch.randn(2, 3, 32, 32, device=DEV)
+    p = K.patchify_fwd(x, 4, torch.float32)
+    assert torch.equal(p.cpu(), O.patch_rearrange(x.cpu(), 4).reshape(-1, 48))
+    d = torch.randn_like(p)
+    back = K.patchify_bwd(d, 2, 3, 32, 4)
+    xr = x.cpu().clone().requires_grad_(True)
+    (O.patch_rearrange(xr, 4).reshape(-1, 48) * d.cpu()).sum().backward()
+    assert torch.equal(back.cpu(), xr.grad)
+
+
+def test_embed_prologue(K):
+    B, N, D = 3, 16, 64
+    tok, cls, pos = torch.randn(B, N, D, device=DEV), torch.randn(D, device=DEV), torch.randn(N + 1, D, device=DEV)
+    x = K.embed_prologue_fwd(tok, cls, pos, B, N, D)
+    ref = torch.cat([cls.expand(B, 1, D), tok], 1) + pos
+    assert torch.equal(x, ref)
+    dx = torch.randn_like(x)
+    dtok, dcls, dpos = K.embed_prologue_bwd(dx, B, N, D, torch.float32)
+    assert torch.equal(dtok.reshape(B, N, D), dx[:, 1:])
+    assert rel_l2(dcls, dx[:, 0].sum(0)) < 1e-6 and rel_l2(dpos, dx.sum(0)) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("L,W,hd,masked", [(5, 3, 16, False), (5, 7, 16, False), (7, 7, 16, True), (12, 7, 64, False),
+                                           (17, 5, 32, True), (65, 7, 64, False), (197, 7, 64, False),
+                                           (197, 15, 16, False), (33, 9, 128, False), (64, 7, 64, False),
+                                           (100, 3, 64, True)])
+def test_mhla_core_fwd_bwd_vs_window_gather(K, dtype, L, W, hd, masked):
+    """The attention core against a direct restatement of the reference's gather-based windows
+    (duplicated pad indices take part in the softmax, models/mhla.py:117-154)."""
+    from oracle import favit_oracle as O
+    B, H = 2, 3
+    D = H * hd
+    g = torch.Generator(device=DEV).manual_seed(L * 31 + W)
+    qkv = _rand((B * L, 3 * D), dtype, g)
+    dout = _rand((B * L, D), dtype, g)
+    mask = None
+    if masked:
+        mask = (torch.rand(B, L, L, generator=g, device=DEV) > 0.4)
+        mask |= torch.eye(L, dtype=torch.bool, device=DEV)
+        mask = mask.to(torch.uint8).contiguous()
+    out = K.mhla_attn_fwd(qkv, B, L, H, hd, W, mask)
+    dqkv = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask)
+    idx = torch.from_numpy(O.window_indices(L, W)).to(DEV)
+    t = qkv.float().reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4).detach().clone().requires_grad_(True)
+    q, k, v = t[0], t[1], t[2]
+    kw, vw = k[:, :, idx], v[:, :, idx]                       # [B,H,L,W,hd]
+    s = (q.unsqueeze(3) @ kw.transpose(-2, -1)).squeeze(3) / (hd ** 0.5)
+    if mask is not None:
+        wm = torch.gather(mask[:, None].expand(B, H, L, L), 3, idx[None, None].expand(B, H, L, W))
+        s = s.masked_fill(wm == 0, float("-inf"))
+    o = (torch.softmax(s, -1).unsqueeze(3) @ vw).squeeze(3).transpose(1, 2).reshape(B * L, D)
+    assert rel_l2(out.float(), o) < _tol(dtype)
+    o.backward(dout.float())
+    gref = t.grad.permute(1, 3, 0, 2, 4).reshape(B * L, 3 * D)
+    assert rel_l2(dqkv.float(), gref) < (5e-5 if dtype == torch.float32 else 1.5e-2)
+
+
+def test_mhla_core_dropout_consistency(K):
+    """Train-mode attention dropout: fwd and bwd use the same mask (finite-difference-free check:
+    out is linear in V, so <dout, out(V)> == <dV, V>)."""
+    B, H, L, hd, W = 2, 2, 40, 16, 7
+    D = H * hd
+    qkv = torch.randn(B * L, 3 * D, device=DEV)
+    dout = torch.randn(B * L, D, device=DEV)
+    out = K.mhla_attn_fwd(qkv, B, L, H, hd, W, None, 0.25, 77)
+    dqkv = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, None, 0.25, 77)
+    lhs = (dout * out).sum().item()
+    rhs = (dqkv[:, 2 * D:] * qkv[:, 2 * D:]).sum().item()
+    assert abs(lhs - rhs) < 1e-3 * max(1.0, abs(lhs))
+    out2 = K.mhla_attn_fwd(qkv, B, L, H, hd, W, None, 0.25, 78)
+    assert not torch.allclose(out, out2)
+
+
+def test_mhla_fold_matches_separate_latent_proj(K):
+    H, hd = 4, 16
+    D = H * hd
+    g = torch.Generator(device=DEV).manual_seed(3)
+    wqkv, bqkv = torch.randn(3 * D, D, generator=g, device=DEV), torch.randn(3 * D, generator=g, device=DEV)
+    wl, bl = torch.randn(hd, hd, generator=g, device=DEV), torch.randn(hd, generator=g, device=DEV)
+    weff, beff = K.mhla_fold_fwd(wqkv, bqkv, wl, bl, H, torch.float32)
+    w, b, l, lb = [t.clone().requires_grad_(True) for t in (wqkv, bqkv, wl, bl)]
+    wk = w.reshape(3, H, hd, D)
+    weff_ref = torch.cat([wk[0].reshape(D, D), (l @ wk[1]).reshape(D, D), (l @ wk[2]).reshape(D, D)])
+    bk = b.reshape(3, H, hd)
+    beff_ref = torch.cat([bk[0].reshape(D), (bk[1] @ l.t() + lb).reshape(D), (bk[2] @ l.t() + lb).reshape(D)])
+    assert rel_l2(weff, weff_ref) < 2e-5 and rel_l2(beff, beff_ref) < 2e-5
+    dweff, dbeff = torch.randn(3 * D, D, generator=g, device=DEV), torch.randn(3 * D, generator=g, device=DEV)
+    ((weff_ref * dweff).sum() + (beff_ref * dbeff).sum()).backward()
+    dwqkv, dbqkv, dwl, dbl = K.mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H)
+    for got, ref in ((dwqkv, w.grad), (dbqkv, b.grad), (dwl, l.grad), (dbl, lb.grad)):
+        assert rel_l2(got, ref) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_softmax_fwd_bwd(K, dtype):
+    Z, Lq, Lk, H = 6, 9, 70, 3
+    g = torch.Generator(device=DEV).manual_seed(21)
+    S = torch.randn(Z, Lq, Lk, generator=g, device=DEV) * 3
+    mask = (torch.rand(Z // H, Lq, Lk, generator=g, device=DEV) > 0.3)
+    mask[..., 0] = True
+    P, Pd = K.softmax_fwd(S, dtype, H, Z, Lq, Lk, mask.to(torch.uint8).contiguous(), Lq * Lk, Lk)
+    Sr = S.clone().requires_grad_(True)
+    ref = torch.softmax(Sr.masked_fill(~mask.repeat_interleave(H, 0), float("-inf")), -1)
+    assert rel_l2(P.float(), ref) < _tol(dtype)
+    dP = torch.randn(Z, Lq, Lk, generator=g, device=DEV)
+    dS = K.softmax_bwd(P, dP, Z, Lq, Lk)
+    ref.backward(dP)
+    assert rel_l2(dS.float(), Sr.grad) < (2e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_cross_entropy_and_adamw(K):
+    B, Cn = 37, 1000
+    logits = torch.randn(B, Cn, device=DEV) * 3
+    labels = torch.randint(0, Cn, (B,), device=DEV)
+    rows, dlog = K.cross_entropy(logits, labels, grad_scale=1.0 / B)
+    lr = logits.clone().requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(lr, labels)
+    loss.backward()
+    assert abs(rows.mean().item() - loss.item()) < 1e-5 and rel_l2(dlog, lr.grad) < 2e-5
+    p = torch.randn(10007, device=DEV)
+    gr = torch.randn_like(p)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=0.05)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in (1, 2, 3):
+        pr.grad = gr.clone()
+        opt.step()
+        K.adamw(p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.05, step)
+    assert rel_l2(p, pr.detach()) < 1e-6
+
+
+def test_sppp_kernels_vs_golden(K):
+    from conftest import case, load_golden
+    SP = load_golden("sppp.npz")
+    emb = torch.from_numpy(SP["emb"]).to(DEV)
+    for nm in ("grid", "vor16", "vor15"):
+        c = case(SP, nm)
+        seg = torch.from_numpy(c["segmap"].astype(np.int64)).to(DEV)
+        rank, ntok, perm, offs, dom = K.sppp_map_patches(seg[None], 16)
+        np.testing.assert_array_equal(rank[0].cpu().numpy(), c["patch_rank"])     # bit-exact integer work
+        R = int(ntok[0].item())
+        assert R == len(c["map_keys"])
+        first = [int(dom[0][(rank[0] == r).nonzero()[0, 0]].item()) for r in range(R)]
+        assert first == c["map_keys"].tolist()
+        for kind, kname in enumerate(("mean", "max", "attention")):
+            out, argmax = K.sppp_pool_fwd(emb[None].contiguous(), perm, offs, kind, R)
+            assert rel_l2(out[0], c[f"pool_{kname}"]) < 2e-5, (nm, kname)
+            gout = torch.from_numpy(c[f"pool_{kname}_gout"]).to(DEV)[None].contiguous()
+            gin = K.sppp_pool_bwd(gout, emb[None].contiguous(), perm, offs, argmax, kind, R)
+            assert rel_l2(gin[0], c[f"pool_{kname}_gin"]) < 2e-5, (nm, kname)
+        segs = torch.stack([seg, torch.roll(seg, 5, dims=1)])
+        cent = K.sppp_centroids(segs, 16)
+        assert rel_l2(cent, c["centroids"]) < 2e-5
+        pe = K.sppp_posenc_fwd(torch.from_numpy(c["posenc_in"]).to(DEV), cent)
+        assert rel_l2(pe, c["posenc_out"]) < 2e-5
+    pe = K.sppp_posenc_fwd(torch.from_numpy(SP["posenc_nocentroid_in"]).to(DEV), None)
+    assert rel_l2(pe, SP["posenc_nocentroid_out"]) < 2e-5

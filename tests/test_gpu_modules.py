@@ -1,0 +1,230 @@
+"""GPU parity of the nn.Module mirrors against the golden vectors captured from the reference
+(tests/golden/*.npz).  fp32 compute mode: forward 1e-4 rel-L2, gradients 5e-4 (north_star:
+logits within 1e-3 rel of the reference); bf16 mode: stated tolerance 2e-2 (the reference itself
+run in bf16 drifts ~1e-2 from its fp32 result)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import case, load_golden, rel_l2, sd_of
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+D, H = 64, 4
+FWD_TOL, GRAD_TOL = 1e-4, 5e-4
+
+
+@pytest.fixture(autouse=True)
+def _fp32_mode(favit):
+    favit.set_compute_dtype("fp32")
+    yield
+    favit.set_compute_dtype("fp32")
+
+
+def _run(module, c, n_in=1, extra=None, fwd_tol=FWD_TOL, grad_tol=GRAD_TOL, check_grads=True):
+    module.load_state_dict(sd_of(c))
+    module.to(DEV).eval()
+    ins = [torch.from_numpy(c[f"in{i}"]).to(DEV).requires_grad_(True) for i in range(n_in)]
+    kw = {k: v.to(DEV) for k, v in (extra or {}).items()}
+    y = module(*ins, **kw)
+    assert rel_l2(y.detach().cpu(), c["out"]) < fwd_tol, "forward"
+    if not check_grads:
+        return
+    (y * torch.from_numpy(c["gout"]).to(DEV)).sum().backward()
+    for i, t in enumerate(ins):
+        assert rel_l2(t.grad.cpu(), c[f"gin{i}"]) < grad_tol, f"grad input {i}"
+    for k, p in module.named_parameters():
+        ref = c[f"grad/{k}"]
+        g = p.grad.cpu() if p.grad is not None else torch.zeros_like(p).cpu()
+        if np.abs(ref).max() < 1e-5:
+            assert g.abs().max().item() < 1e-4, k
+        else:
+            assert rel_l2(g, ref) < grad_tol, f"grad {k}: {rel_l2(g, ref)}"
+
+
+MHLA = load_golden("mhla.npz")
+VP = load_golden("vit_parts.npz")
+CR = load_golden("cross.npz")
+SP = load_golden("sppp.npz")
+MD = load_golden("models.npz")
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in MHLA.files if k.startswith("attn_L")}))
+def test_mhla_attention(favit, name):
+    W = int(name.split("_W")[1])
+    _run(favit.models.mhla.MultiHeadLatentAttention(D, H, window_size=W), case(MHLA, name))
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in MHLA.files if k.startswith("attn_mask")}))
+def test_mhla_attention_masked(favit, name):
+    W = int(name.split("_W")[1])
+    c = case(MHLA, name)
+    _run(favit.models.mhla.MultiHeadLatentAttention(D, H, window_size=W), c,
+         extra={"attention_mask": torch.from_numpy(c["attention_mask"])})
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in MHLA.files if k.startswith("block_")}))
+def test_mhla_block(favit, name):
+    W = int(name.split("_W")[1])
+    _run(favit.models.mhla.MHLATransformerBlock(D, H, window_size=W), case(MHLA, name))
+
+
+def test_even_window_is_a_clear_error(favit):
+    m = favit.models.mhla.MultiHeadLatentAttention(D, H, window_size=4).to(DEV)
+    with pytest.raises(ValueError):
+        m(torch.randn(1, 12, D, device=DEV))
+
+
+@pytest.mark.parametrize("name", ["mha_L5", "mha_L17", "mha_L65"])
+def test_dense_mha(favit, name):
+    _run(favit.models.vit.MultiHeadAttention(D, H), case(VP, name))
+
+
+def test_mlp(favit):
+    _run(favit.models.vit.MLP(D, 4 * D, D), case(VP, "mlp"))
+
+
+def test_vit_block(favit):
+    _run(favit.models.vit.TransformerBlock(D, H), case(VP, "block_L17"))
+
+
+def test_patch_embedding(favit):
+    _run(favit.models.vit.PatchEmbedding(img_size=32, patch_size=4, in_channels=3, embed_dim=D), case(VP, "patch_embed"))
+
+
+@pytest.mark.parametrize("use_mhla", [0, 1])
+@pytest.mark.parametrize("L", [17, 65])
+def test_vit_mhla_block(favit, use_mhla, L):
+    _run(favit.models.vit_mhla.TransformerBlock(D, H, window_size=7, use_mhla=bool(use_mhla)),
+         case(VP, f"vm_block_mhla{use_mhla}_L{L}"))
+
+
+@pytest.mark.parametrize("masked", [0, 1])
+@pytest.mark.parametrize("kind", ["ca", "mhca"])
+def test_cross_attention(favit, kind, masked):
+    c = case(CR, f"{kind}_mask{masked}")
+    A = favit.models.attention
+    m = A.CrossAttention(D) if kind == "ca" else A.MultiHeadCrossAttention(D, H)
+    extra = {"attention_mask": torch.from_numpy(c["attention_mask"])} if masked else None
+    _run(m, c, n_in=2, extra=extra)
+
+
+@pytest.mark.parametrize("mh", [0, 1])
+def test_cross_block(favit, mh):
+    _run(favit.models.attention.CrossAttentionTransformerBlock(D, H, use_multi_head=bool(mh)), case(CR, f"block_mh{mh}"),
+         n_in=2)
+
+
+def test_bf16_mode_block_within_stated_tolerance(favit):
+    favit.set_compute_dtype("bf16")
+    _run(favit.models.mhla.MHLATransformerBlock(D, H, window_size=7), case(MHLA, "block_L17_W7"), fwd_tol=2e-2,
+         grad_tol=4e-2)
+
+
+@pytest.mark.parametrize("nm", ["grid", "vor16", "vor15"])
+def test_sppp_model_logits(favit, nm):
+    c = case(SP, nm)
+    seg = torch.from_numpy(c["segmap"].astype(np.int64))
+    segs = torch.stack([seg, torch.roll(seg, 5, dims=1)]).to(DEV)
+    m = favit.models.sppp_mhla.SPPPViTMHLA(img_size=224, patch_size=16, num_classes=10, embed_dim=D, depth=2,
+                                          num_heads=H, num_superpixels=16, pooling_type="mean", window_size=7,
+                                          use_mhla=True)
+    m.load_state_dict(sd_of(c))
+    m.to(DEV).eval()
+    m.segmentation.set_label_maps(segs)
+    x = torch.from_numpy(c["model_x"].astype(np.float32)).to(DEV)
+    y = m(x)
+    assert rel_l2(y.detach().cpu(), c["logits"]) < 1e-3
+    y.sum().backward()          # the whole SPPP graph is differentiable through the kernels
+    assert m.patch_embed.projection[1].weight.grad.abs().sum().item() > 0
+
+
+def test_sppp_reference_dict_api(favit):
+    c = case(SP, "vor16")
+    seg = torch.from_numpy(c["segmap"].astype(np.int64)).to(DEV)
+    S = favit.models.sppp
+    mapping = S.PatchToSuperpixelMapper(16).map_patches(seg, 224)
+    assert list(mapping.keys()) == c["map_keys"].tolist()
+    emb = torch.from_numpy(SP["emb"]).to(DEV)
+    for kind in ("mean", "max", "attention"):
+        out = S.SuperpixelPooling(kind).pool(emb, mapping)
+        assert rel_l2(out.cpu(), c[f"pool_{kind}"]) < 2e-5
+    with pytest.raises(ValueError):
+        S.SuperpixelPooling("median").pool(emb, mapping)
+
+
+def _model_check(favit, model, x, y, key, tol_logits, tol_loss, tol_gn):
+    model.to(DEV).eval()
+    logits = model(x.to(DEV))
+    ref = MD[f"{key}/logits"]
+    assert rel_l2(logits.detach().cpu(), ref) < tol_logits, rel_l2(logits.detach().cpu(), ref)
+    loss = favit.train.cross_entropy(logits, y.to(DEV))
+    assert abs(loss.item() - float(MD[f"{key}/loss"])) < tol_loss * abs(float(MD[f"{key}/loss"]))
+    loss.backward()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        gn = p.grad.norm().item()
+        r = float(MD[f"{key}/gnorm/{k}"])
+        worst = max(worst, abs(gn - r) / max(r, 1e-12))
+    assert worst < tol_gn, worst
+
+
+def test_cfg1_vit_tiny_logits_loss_gradnorms(favit):
+    """BASELINE.json configs[0]: ViT-Tiny 32x32 patch4, seed-initialised (a24: same RNG order)."""
+    torch.manual_seed(1234)
+    m = favit.models.vit.VisionTransformer(img_size=32, patch_size=4, num_classes=10, embed_dim=192, depth=12,
+                                           num_heads=3)
+    _model_check(favit, m, torch.from_numpy(MD["cfg1/x"]), torch.from_numpy(MD["cfg1/y"]), "cfg1", 1e-3, 1e-4, 2e-3)
+
+
+@pytest.mark.parametrize("mode,tl,tg", [("fp32", 1e-3, 2e-3), ("bf16", 2e-2, 5e-2)])
+def test_cfg2_vit_mhla_small_logits_loss_gradnorms(favit, mode, tl, tg):
+    """BASELINE.json configs[1]: ViT-MHLA-Small 224/p16, 197 tokens; weights and inputs are
+    regenerated from seed 1234 exactly as tests/golden/make_golden.py did."""
+    torch.manual_seed(1234)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384,
+                                                    depth=12, num_heads=6, window_size=7, use_mhla=True)
+    x = torch.randn(2, 3, 224, 224)
+    y = torch.randint(0, 1000, (2,))
+    assert abs(x.double().sum().item() - float(MD["cfg2/x_sum"])) < 1e-6 and torch.equal(y, torch.from_numpy(MD["cfg2/y"]))
+    favit.set_compute_dtype(mode)
+    _model_check(favit, m, x, y, "cfg2", tl, tl, tg)
+
+
+def test_use_mhla_false_fallback_model(favit):
+    torch.manual_seed(1234)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2,
+                                                    num_heads=4, use_mhla=False)
+    m.to(DEV).eval()
+    y = m(torch.from_numpy(MD["fallback/x"]).to(DEV))
+    assert rel_l2(y.detach().cpu(), MD["fallback/logits"]) < 1e-3
+
+
+def test_train_mode_dropout_runs_and_is_stochastic(favit):
+    torch.manual_seed(0)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2,
+                                                    num_heads=4, dropout=0.1, attn_dropout=0.1, embed_dropout=0.1,
+                                                    use_mhla=True).to(DEV)
+    x = torch.randn(4, 3, 32, 32, device=DEV)
+    m.train()
+    a, b = m(x), m(x)
+    assert not torch.allclose(a, b)
+    a.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    m.eval()
+    assert torch.equal(m(x), m(x))
+
+
+def test_full_size_cfg2_batch_independence(favit):
+    """BASELINE.json configs[1] at its full size (B=256, bf16): every image is independent, so the
+    logits of images 0..1 inside the batch of 256 equal the logits of the batch of 2."""
+    favit.set_compute_dtype("bf16")
+    torch.manual_seed(1234)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384,
+                                                    depth=12, num_heads=6, window_size=7, use_mhla=True).to(DEV).eval()
+    x = torch.randn(256, 3, 224, 224, device=DEV)
+    with torch.no_grad():
+        big = m(x)
+        small = m(x[:2].contiguous())
+    assert torch.isfinite(big).all()
+    assert rel_l2(big[:2].cpu(), small.cpu()) < 1e-5
