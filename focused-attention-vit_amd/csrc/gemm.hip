@@ -558,10 +558,13 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   const long tiles_m = (g->M + BM - 1) / BM, tiles_n = (g->N + BN - 1) / BN;
   const long tiles = tiles_m * tiles_n * batch;
   long splits = g->split_k;
-  const bool can_split = (g->out_dtype == FAVIT_F32) && g->act == FAVIT_ACT_NONE && !g->aux_out;
+  const bool can_split = (g->out_dtype == FAVIT_F32) && g->act == FAVIT_ACT_NONE && !g->aux_out &&
+                         !(g->dropout_p > 0.f);
   if (splits <= 0) {
     splits = 1;
-    if (can_split && tiles < 256 && g->K >= 8 * bk) {
+    // automatic split-K only for the weight-gradient shape (both operands mn-major, K = tokens):
+    // forward / input-gradient GEMMs stay single-pass and therefore bitwise deterministic.
+    if (can_split && !g->a_kmajor && !g->b_kmajor && tiles < 256 && g->K >= 8 * bk) {
       splits = (512 + tiles - 1) / tiles;
       const long max_splits = g->K / (4 * bk);
       if (splits > max_splits) splits = max_splits;

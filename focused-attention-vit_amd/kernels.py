@@ -17,6 +17,11 @@ from ._abi import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, GemmDesc
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
+# bench.py sets this to a list to time every favit_gemm launch with HIP events recorded on the
+# stream the kernel is launched on (torch's current stream): entries are
+# (start_event, end_event, algorithmic_flops, kernel_key).
+GEMM_TRACE = None
+
 
 def dt(t_or_dtype) -> int:
     d = t_or_dtype.dtype if torch.is_tensor(t_or_dtype) else t_or_dtype
@@ -80,7 +85,16 @@ def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias
         raise TypeError("bias must be fp32")
     if residual is not None and residual.dtype != torch.float32:
         raise TypeError("residual must be fp32")
+    if GEMM_TRACE is None:
+        _abi.check(_abi.lib().favit_gemm(C.byref(d), _st()), "favit_gemm")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _abi.check(_abi.lib().favit_gemm(C.byref(d), _st()), "favit_gemm")
+    e1.record()
+    key = ("bf16" if A.dtype == torch.bfloat16 else "f32") + ("_K" if a_kmajor else "_M") + ("K" if b_kmajor else "M") + \
+          ("_obf16" if Cc.dtype == torch.bfloat16 else "_of32")
+    GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, key, (M, N, K, batch)))
 
 
 def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -46,7 +46,7 @@ def sd_of(c):
 
 
 def rel_l2(a, b):
-    a = torch.as_tensor(a, dtype=torch.float64).flatten()
-    b = torch.as_tensor(b, dtype=torch.float64).flatten()
+    a = torch.as_tensor(a).detach().cpu().to(torch.float64).flatten()
+    b = torch.as_tensor(b).detach().cpu().to(torch.float64).flatten()
     den = b.norm().item()
     return (a - b).norm().item() / (den if den > 0 else 1.0)

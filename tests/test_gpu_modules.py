@@ -215,10 +215,12 @@ def test_train_mode_dropout_runs_and_is_stochastic(favit):
     assert torch.equal(m(x), m(x))
 
 
-def test_full_size_cfg2_batch_independence(favit):
-    """BASELINE.json configs[1] at its full size (B=256, bf16): every image is independent, so the
-    logits of images 0..1 inside the batch of 256 equal the logits of the batch of 2."""
-    favit.set_compute_dtype("bf16")
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
+def test_full_size_cfg2_batch_independence(favit, mode, tol):
+    """BASELINE.json configs[1] at its full size (B=256): every image is independent, so the
+    logits of images 0..1 inside the batch of 256 equal the logits of the batch of 2 (bf16: up to
+    rounding flips, stated tolerance 2e-2)."""
+    favit.set_compute_dtype(mode)
     torch.manual_seed(1234)
     m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384,
                                                     depth=12, num_heads=6, window_size=7, use_mhla=True).to(DEV).eval()
@@ -227,4 +229,4 @@ def test_full_size_cfg2_batch_independence(favit):
         big = m(x)
         small = m(x[:2].contiguous())
     assert torch.isfinite(big).all()
-    assert rel_l2(big[:2].cpu(), small.cpu()) < 1e-5
+    assert rel_l2(big[:2].cpu(), small.cpu()) < tol
