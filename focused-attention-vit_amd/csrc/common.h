@@ -40,6 +40,31 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
+// Fast GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16
+// resolution), one v_exp + one v_rcp instead of libm erff.  phi/Phi share the exponential.
+__device__ __forceinline__ void gelu_terms_fast(float x, float& cdf, float& pdf) {
+  const float ax = fabsf(x);
+  const float e = __expf(-0.5f * x * x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erfa = 1.0f - poly * t * e;            // erf(|x|/sqrt2)
+  cdf = 0.5f * (1.0f + copysignf(erfa, x));
+  pdf = 0.39894228040143267794f * e;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  float c, p;
+  gelu_terms_fast(x, c, p);
+  return x * c;
+}
+__device__ __forceinline__ float dgelu_fast(float x) {
+  float c, p;
+  gelu_terms_fast(x, c, p);
+  return fmaf(x, p, c);
+}
+
 // Counter-based RNG for dropout: one 32-bit draw per (seed, index); the same draw is
 // recomputed in backward, so no mask is stored.  (splitmix64 finaliser)
 __device__ __forceinline__ uint32_t favit_rand_u32(uint64_t seed, uint64_t idx) {

@@ -16,6 +16,7 @@
 // up with 4 consecutive n for one m: the accumulators go to LDS as float4 and the
 // epilogue (bias / GELU / dGELU / residual / atomics) runs on full coalesced rows.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -53,6 +54,8 @@ struct KParams {
   uint32_t drop_thresh;
   float drop_scale;
   uint64_t drop_seed;
+  int stagger_ticks;   // 100 MHz ticks the second resident set of p4 workgroups waits at start
+  int dbg;     // experiments only (FAVIT_GEMM_DBG): 1 = skip epilogue, 2 = skip main loop
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -155,14 +158,21 @@ __device__ __forceinline__ bf16x8 load_frag16(const char* lds, int r0, int ks, i
 __device__ __forceinline__ int epi_off(int row, int col) {
   return row * EPI_LD + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3));
 }
-template <typename InT, typename OutT>
+template <typename InT> __device__ __forceinline__ float epi_gelu(float v) {
+  if constexpr (sizeof(InT) == 2) return gelu_fast(v); else return gelu_f(v);
+}
+template <typename InT> __device__ __forceinline__ float epi_dgelu(float v) {
+  if constexpr (sizeof(InT) == 2) return dgelu_fast(v); else return dgelu_f(v);
+}
+
+template <typename InT, typename OutT, int TBM = BM, int NT = NTHREADS>
 __device__ __forceinline__ void run_epilogue(const KParams& p, const float* epi, long m0, long n0, OutT* C,
                                              bool first_split, int tid) {
-  const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  const bool full_tile = (m0 + TBM <= p.M) && (n0 + BN <= p.N);
   if (p.c_vec && !p.atomic && full_tile) {
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int c = tid + NTHREADS * it;
+    for (int it = 0; it < TBM * BN / 4 / NT; ++it) {
+      const int c = tid + NT * it;
       const int row = c >> 5, c4 = (c & 31) * 4;
       const long m = m0 + row, n = n0 + c4;
       float4 v = *reinterpret_cast<const float4*>(epi + epi_off(row, c4));
@@ -182,7 +192,7 @@ __device__ __forceinline__ void run_epilogue(const KParams& p, const float* epi,
       }
       if (p.act == FAVIT_ACT_GELU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] = gelu_f(a[j]);
+        for (int j = 0; j < 4; ++j) a[j] = epi_gelu<InT>(a[j]);
       } else if (p.act == FAVIT_ACT_DGELU) {
         const InT* ai = reinterpret_cast<const InT*>(p.aux_in) + m * p.ld_aux_in + n;
         float x[4];
@@ -194,7 +204,7 @@ __device__ __forceinline__ void run_epilogue(const KParams& p, const float* epi,
           x[0] = (float)t[0]; x[1] = (float)t[1]; x[2] = (float)t[2]; x[3] = (float)t[3];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] *= dgelu_f(x[j]);
+        for (int j = 0; j < 4; ++j) a[j] *= epi_dgelu<InT>(x[j]);
       }
       if (p.drop_thresh) {
 #pragma unroll
@@ -217,17 +227,17 @@ __device__ __forceinline__ void run_epilogue(const KParams& p, const float* epi,
     // scalar path: ragged tiles, unaligned leading dims, or fp32 atomics (split-K /
     // accumulate).  Lanes walk one row contiguously: an atomic wave-instruction adds
     // 256 contiguous bytes.
-    for (int it = 0; it < 64; ++it) {
-      const int c = tid + NTHREADS * it;
+    for (int it = 0; it < TBM * BN / NT; ++it) {
+      const int c = tid + NT * it;
       const int row = c >> 7, col = c & 127;
       const long m = m0 + row, n = n0 + col;
       if (m >= p.M || n >= p.N) continue;
       float v = epi[epi_off(row, col)] * p.alpha;
       if (first_split && p.bias) v += p.bias[n];
       if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n] = from_f32<OutT>(v);
-      if (p.act == FAVIT_ACT_GELU) v = gelu_f(v);
+      if (p.act == FAVIT_ACT_GELU) v = epi_gelu<InT>(v);
       else if (p.act == FAVIT_ACT_DGELU)
-        v *= dgelu_f(to_f32(reinterpret_cast<const InT*>(p.aux_in)[m * p.ld_aux_in + n]));
+        v *= epi_dgelu<InT>(to_f32(reinterpret_cast<const InT*>(p.aux_in)[m * p.ld_aux_in + n]));
       if (p.drop_thresh) v = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n), p.drop_thresh) ? v * p.drop_scale : 0.f;
       if (first_split && p.residual) v += p.residual[m * p.ld_res + n];
       if (p.atomic) {
@@ -349,6 +359,661 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(KParams p) {
       if (m < p.M) atomicAdd(p.a_rowsum + m, s);
     }
   }
+}
+
+// --------------------------------------------------------------------------------------
+// bf16 kernel, direct-to-LDS staging (global_load_lds_dwordx4): no VGPR round trip and no
+// ds_write pass.  A wave-instruction lands 1 KiB contiguously (wave-uniform LDS base +
+// lane*16), so the LDS image stays linear and the XOR swizzle is applied to the per-lane
+// SOURCE address (and again on the fragment read).  Used when every K-range is a multiple of
+// 64 and operands are 16-B aligned; rows past the M/N edge are clamped (their outputs are
+// never stored).  The bias-gradient row sums come from one extra MFMA per A fragment against
+// an all-ones fragment.
+// --------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// source pointer of this lane for 1-KiB piece q (0..15) of a 128-wide operand image
+template <bool KMAJOR>
+__device__ __forceinline__ const bf16_t* glds_src(const bf16_t* base, long ld, long i0, long I, long k0, int q, int lane) {
+  if (KMAJOR) {
+    const int row = 8 * q + (lane >> 3), pc = lane & 7;
+    const int c = pc ^ ((row >> 1) & 7);
+    long i = i0 + row;
+    i = i < I ? i : I - 1;
+    return base + i * ld + k0 + c * 8;
+  } else {
+    const int krow = 4 * q + (lane >> 4), pc = lane & 15;
+    const int c = pc ^ (hsw(krow) << 1);
+    long i = i0 + c * 8;
+    const long imax = (I - 8) & ~7L;
+    i = i < imax ? i : imax;
+    return base + (k0 + krow) * ld + i;
+  }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void glds_setup(const bf16_t* base, long ld, long i0, long I, long k0, int wave, int lane,
+                                           const bf16_t* (&src)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = wave * 4 + j;
+    if (KMAJOR) {
+      const int row = 8 * q + (lane >> 3), pc = lane & 7;
+      const int c = pc ^ ((row >> 1) & 7);
+      long i = i0 + row;
+      i = i < I ? i : I - 1;
+      src[j] = base + i * ld + k0 + c * 8;
+    } else {
+      const int krow = 4 * q + (lane >> 4), pc = lane & 15;
+      const int c = pc ^ (hsw(krow) << 1);
+      long i = i0 + c * 8;
+      const long imax = (I - 8) & ~7L;
+      i = i < imax ? i : imax;
+      src[j] = base + (k0 + krow) * ld + i;
+    }
+  }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void glds_issue(const bf16_t* (&src)[4], char* tile, int wave, long ld) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src[j], (lptr_t)(tile + (wave * 4 + j) * 1024), 16, 0, 0);
+    src[j] += KMAJOR ? BK16 : BK16 * ld;
+  }
+}
+
+template <bool AK, bool BKM, typename OutT>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_glds_kernel(KParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long m0 = (long)(tile / p.tiles_n) * BM;
+  const long n0 = (long)(tile % p.tiles_n) * BN;
+  const int z = blockIdx.z;
+  const long zo = z / p.batch_inner, zi = z % p.batch_inner;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
+  const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
+  OutT* C = reinterpret_cast<OutT*>(p.C) + zo * p.sCo + zi * p.sCi;
+
+  const long kbeg = (long)blockIdx.y * p.k_per_split;
+  const long kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (int)((kend - kbeg) / BK16);
+
+  auto ldsA = [&](int b) { return smem + (2 * b) * OP16_BYTES; };
+  auto ldsB = [&](int b) { return smem + (2 * b + 1) * OP16_BYTES; };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0) && (wc == 0);
+  f32x4 racc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) racc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+
+  const bf16_t* sa[4];
+  const bf16_t* sb[4];
+  glds_setup<AK>(A, p.lda, m0, p.M, kbeg, wave, lane, sa);
+  glds_setup<BKM>(Bm, p.ldb, n0, p.N, kbeg, wave, lane, sb);
+  if (nk > 0) {
+    glds_issue<AK>(sa, ldsA(0), wave, p.lda);
+    glds_issue<BKM>(sb, ldsB(0), wave, p.ldb);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      glds_issue<AK>(sa, ldsA(cur ^ 1), wave, p.lda);
+      glds_issue<BKM>(sb, ldsB(cur ^ 1), wave, p.ldb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = load_frag16<AK>(ldsA(cur), wr * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = load_frag16<BKM>(ldsB(cur), wc * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      if (do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) racc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], racc[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  float* epi = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = wr * 64 + i * 16 + (lane & 15);
+      const int n = wc * 64 + j * 16 + 4 * (lane >> 4);
+      *reinterpret_cast<f32x4*>(epi + epi_off(m, n)) = acc[i][j];
+    }
+  __syncthreads();
+  run_epilogue<bf16_t, OutT>(p, epi, m0, n0, C, blockIdx.y == 0, tid);
+
+  if (do_rowsum && lane < 16) {
+    // D[i][j] of the ones-MFMA = rowsum(A[m0 + wr*64 + 16*t + j]) for every i: take row 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long m = m0 + wr * 64 + i * 16 + lane;
+      if (m < p.M) atomicAdd(p.a_rowsum + m, racc[i][0]);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------
+// bf16 kernel, 256x128 tile, 8 waves (4x2, 64x64 each), THREE LDS stages of 48 KiB filled by
+// global_load_lds with a counted s_waitcnt vmcnt(6): while stage kt is consumed, stages kt+1
+// and kt+2 are in flight (96 KiB per CU), which is what the ~1.5 us loaded L2/HBM latency
+// needs (the 2-stage loop is latency-bound: one vmcnt(0) + barrier per K-step).
+// One raw s_barrier per K-step.  LDS: 3 x (A0 | A1 | B) x 16 KiB = 144 KiB, reused as the
+// fp32 epilogue image [256][128].
+// --------------------------------------------------------------------------------------
+constexpr int P3_BM = 256;
+constexpr int P3_THREADS = 512;
+constexpr int P3_STAGE = 3 * OP16_BYTES;          // 48 KiB
+constexpr int P3_LDS = 3 * P3_STAGE;              // 147456
+
+template <bool AK, bool BKM, typename OutT>
+__global__ __launch_bounds__(P3_THREADS) void gemm_bf16_p3_kernel(KParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;                  // 4 x 2 waves
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long m0 = (long)(tile / p.tiles_n) * P3_BM;
+  const long n0 = (long)(tile % p.tiles_n) * BN;
+  const int z = blockIdx.z;
+  const long zo = z / p.batch_inner, zi = z % p.batch_inner;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
+  const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
+  OutT* C = reinterpret_cast<OutT*>(p.C) + zo * p.sCo + zi * p.sCi;
+
+  const long kbeg = (long)blockIdx.y * p.k_per_split;
+  const long kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = p.dbg == 2 ? 0 : (int)((kend - kbeg) / BK16);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0) && (wc == 0);
+  f32x4 racc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) racc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+
+  // this wave's 6 pieces per stage: 4 of A (32 pieces = 2 sub-images x 16), 2 of B (16 pieces)
+  const bf16_t* sa[4];
+  const bf16_t* sb[2];
+  int da[4], db[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int qa = wave * 4 + j, sub = qa >> 4, q = qa & 15;
+    sa[j] = glds_src<AK>(A, p.lda, m0 + sub * 128, p.M, kbeg, q, lane);
+    da[j] = sub * OP16_BYTES + q * 1024;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = wave * 2 + j;
+    sb[j] = glds_src<BKM>(Bm, p.ldb, n0, p.N, kbeg, q, lane);
+    db[j] = 2 * OP16_BYTES + q * 1024;
+  }
+  auto issue = [&](int buf) {
+    char* st = smem + buf * P3_STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + da[j]), 16, 0, 0);
+      sa[j] += AK ? BK16 : BK16 * p.lda;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sb[j], (lptr_t)(st + db[j]), 16, 0, 0);
+      sb[j] += BKM ? BK16 : BK16 * p.ldb;
+    }
+  };
+
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);          // (kt+2) % 3
+    const char* st = smem + cur * P3_STAGE;
+    const char* la = st + (wr >> 1) * OP16_BYTES;
+    const char* lb = st + 2 * OP16_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = load_frag16<AK>(la, (wr & 1) * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = load_frag16<BKM>(lb, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      if (do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) racc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], racc[i], 0, 0, 0);
+      }
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  __syncthreads();
+  if (p.dbg == 1) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 12345.678f) C[0] = from_f32<OutT>(s);
+    return;
+  }
+
+  float* epi = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = wr * 64 + i * 16 + (lane & 15);
+      const int n = wc * 64 + j * 16 + 4 * (lane >> 4);
+      *reinterpret_cast<f32x4*>(epi + epi_off(m, n)) = acc[i][j];
+    }
+  __syncthreads();
+  run_epilogue<bf16_t, OutT, P3_BM, P3_THREADS>(p, epi, m0, n0, C, blockIdx.y == 0, tid);
+
+  if (do_rowsum && lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long m = m0 + wr * 64 + i * 16 + lane;
+      if (m < p.M) atomicAdd(p.a_rowsum + m, racc[i][0]);
+    }
+  }
+}
+
+template <typename Kn>
+int launch_p3(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P3_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(P3_THREADS), P3_LDS, st, kp);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// bf16 kernel "p4": 256x128 tile, 8 waves, BK = 32, three 24-KiB LDS stages (72 KiB -> TWO
+// workgroups per CU) and an epilogue that runs straight from the accumulator registers (no
+// LDS staging, no barrier): one workgroup's prologue / epilogue / store drain overlaps the
+// other's MFMA loop.  Measured on the K=384 shapes of this path the LDS-staged epilogue of a
+// lone workgroup cost as much as the whole main loop.
+//   k-major image : [rows][32 k]  (64-B rows), 16-B chunk c stored at c ^ ((-(row>>2)) & 3)
+//   mn-major image: [32 k][128 i] (256-B rows), same 32-B XOR swizzle as the BK=64 image
+// Lane l of an accumulator tile holds C[m = l&15][n = 4*(l>>4) .. +3]: 8-B (bf16) / 16-B (f32)
+// stores, 16 rows per wave-instruction; the four n-tiles of a wave complete 128-B lines.
+// --------------------------------------------------------------------------------------
+constexpr int P4_BM = 256;
+constexpr int P4_BK = 32;
+constexpr int P4_THREADS = 512;
+constexpr int P4_A_BYTES = 256 * 64;               // 16 KiB
+constexpr int P4_B_BYTES = 128 * 64;               // 8 KiB
+constexpr int P4_STAGE = P4_A_BYTES + P4_B_BYTES;  // 24 KiB
+constexpr int P4_LDS = 3 * P4_STAGE;               // 73728
+
+__device__ __forceinline__ int ksw32(int row) { return (-(row >> 2)) & 3; }
+
+// source pointer for 1-KiB piece q of a BK=32 image.  K-major: piece = 16 rows x 64 B (any number
+// of rows); mn-major: piece = 4 k-rows x 256 B of a 128-wide sub-image (8 pieces).
+template <bool KMAJOR>
+__device__ __forceinline__ const bf16_t* glds_src32(const bf16_t* base, long ld, long i0, long I, long k0, int q, int lane) {
+  if (KMAJOR) {
+    const int row = 16 * q + (lane >> 2), pc = lane & 3;
+    const int c = pc ^ ksw32(row);
+    long i = i0 + row;
+    i = i < I ? i : I - 1;
+    return base + i * ld + k0 + c * 8;
+  } else {
+    const int krow = 4 * q + (lane >> 4), pc = lane & 15;
+    const int c = pc ^ (hsw(krow) << 1);
+    long i = i0 + c * 8;
+    const long imax = (I - 8) & ~7L;
+    i = i < imax ? i : imax;
+    return base + (k0 + krow) * ld + i;
+  }
+}
+
+// fragment (16 rows from r0, all 32 k of the stage)
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8 load_frag32(const char* lds, int r0, int lane) {
+  if (KMAJOR) {
+    const int row = r0 + (lane & 15);
+    const int c = lane >> 4;
+    return *reinterpret_cast<const bf16x8*>(lds + row * 64 + ((c ^ ksw32(row)) << 4));
+  } else {
+    return load_frag16<false>(lds, r0, 0, lane);
+  }
+}
+
+template <typename InT, typename OutT>
+__device__ __forceinline__ void direct_epilogue(const KParams& p, const f32x4 (&acc)[4][4], OutT* C, long mbase,
+                                                long nbase, int lane) {
+  const int lm = lane & 15, ln = 4 * (lane >> 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long n = nbase + j * 16 + ln;
+    if (n >= p.N) continue;
+    const bool nvec = p.c_vec && (n + 4 <= p.N);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      if (nvec) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        bv[0] = b.x; bv[1] = b.y; bv[2] = b.z; bv[3] = b.w;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long m = mbase + i * 16 + lm;
+      if (m >= p.M) continue;
+      float a[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = fmaf(acc[i][j][r], p.alpha, bv[r]);
+      if (nvec) {
+        if (p.aux_out) {
+          OutT* ao = reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n;
+          if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float4*>(ao) = make_float4(a[0], a[1], a[2], a[3]);
+          else { bf16x4 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]}; *reinterpret_cast<bf16x4*>(ao) = o; }
+        }
+        if (p.act == FAVIT_ACT_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] = epi_gelu<InT>(a[r]);
+        } else if (p.act == FAVIT_ACT_DGELU) {
+          const InT* ai = reinterpret_cast<const InT*>(p.aux_in) + m * p.ld_aux_in + n;
+          float x[4];
+          if constexpr (sizeof(InT) == 4) { const float4 t = *reinterpret_cast<const float4*>(ai); x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w; }
+          else { const bf16x4 t = *reinterpret_cast<const bf16x4*>(ai); x[0] = (float)t[0]; x[1] = (float)t[1]; x[2] = (float)t[2]; x[3] = (float)t[3]; }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] *= epi_dgelu<InT>(x[r]);
+        }
+        if (p.drop_thresh) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            a[r] = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n + r), p.drop_thresh) ? a[r] * p.drop_scale : 0.f;
+        }
+        if (p.residual) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.residual + m * p.ld_res + n);
+          a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w;
+        }
+        OutT* co = C + m * p.ldc + n;
+        if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float4*>(co) = make_float4(a[0], a[1], a[2], a[3]);
+        else { bf16x4 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]}; *reinterpret_cast<bf16x4*>(co) = o; }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= p.N) continue;
+          float v = a[r];
+          if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n + r] = from_f32<OutT>(v);
+          if (p.act == FAVIT_ACT_GELU) v = epi_gelu<InT>(v);
+          else if (p.act == FAVIT_ACT_DGELU)
+            v *= epi_dgelu<InT>(to_f32(reinterpret_cast<const InT*>(p.aux_in)[m * p.ld_aux_in + n + r]));
+          if (p.drop_thresh) v = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n + r), p.drop_thresh) ? v * p.drop_scale : 0.f;
+          if (p.residual) v += p.residual[m * p.ld_res + n + r];
+          C[m * p.ldc + n + r] = from_f32<OutT>(v);
+        }
+      }
+    }
+  }
+}
+
+// Epilogue through a WAVE-PRIVATE LDS transpose (no workgroup barrier): the wave's 64x64
+// accumulator block goes through LDS in two 32-row halves so that every global access is a full
+// row segment (64 cols = 128 B bf16 / 256 B f32 contiguous per row, 16 B per lane) instead of the
+// 32-B pieces of the raw MFMA layout (which measured 1.7 TB/s on the two-output fc1 epilogue).
+constexpr int WEPI_LD = 68;                         // padded fp32 row
+constexpr int WEPI_BYTES = 32 * WEPI_LD * 4;        // 8704 B per wave
+
+template <typename InT, typename OutT>
+__device__ __forceinline__ void wave_epilogue(const KParams& p, const f32x4 (&acc)[4][4], OutT* C, long mbase,
+                                              long nbase, int lane, float* wl) {
+  const bool fast = p.c_vec && (nbase + 64 <= p.N);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(wl + (ii * 16 + (lane & 15)) * WEPI_LD + j * 16 + 4 * (lane >> 4)) = acc[half * 2 + ii][j];
+    // (same wave wrote and reads: the compiler's lgkmcnt wait orders them; no barrier needed)
+    constexpr int CPL = sizeof(OutT) == 2 ? 8 : 4;          // columns per lane (16 B of output)
+    constexpr int LPR = 64 / CPL;                           // lanes per row
+    constexpr int RPI = 64 / LPR;                           // rows per iteration
+    const int lr = lane / LPR, lc = (lane % LPR) * CPL;
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int row = it * RPI + lr;
+      const long m = mbase + half * 32 + row, n = nbase + lc;
+      if (m >= p.M) continue;
+      float a[CPL];
+#pragma unroll
+      for (int c4 = 0; c4 < CPL / 4; ++c4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * WEPI_LD + lc + 4 * c4);
+        a[4 * c4] = t[0]; a[4 * c4 + 1] = t[1]; a[4 * c4 + 2] = t[2]; a[4 * c4 + 3] = t[3];
+      }
+      if (fast) {
+#pragma unroll
+        for (int c4 = 0; c4 < CPL / 4; ++c4) {
+          float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + n + 4 * c4);
+          a[4 * c4] = fmaf(a[4 * c4], p.alpha, b.x); a[4 * c4 + 1] = fmaf(a[4 * c4 + 1], p.alpha, b.y);
+          a[4 * c4 + 2] = fmaf(a[4 * c4 + 2], p.alpha, b.z); a[4 * c4 + 3] = fmaf(a[4 * c4 + 3], p.alpha, b.w);
+        }
+        auto store_vec = [&](OutT* dst) {
+          if constexpr (sizeof(OutT) == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(a[0], a[1], a[2], a[3]);
+          } else {
+            bf16x8 o;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] = (bf16_t)a[c];
+            *reinterpret_cast<bf16x8*>(dst) = o;
+          }
+        };
+        if (p.aux_out) store_vec(reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n);
+        if (p.act == FAVIT_ACT_GELU) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) a[c] = epi_gelu<InT>(a[c]);
+        } else if (p.act == FAVIT_ACT_DGELU) {
+          const InT* ai = reinterpret_cast<const InT*>(p.aux_in) + m * p.ld_aux_in + n;
+          float x[CPL];
+          if constexpr (sizeof(InT) == 4) {
+#pragma unroll
+            for (int c4 = 0; c4 < CPL / 4; ++c4) {
+              const float4 t = *reinterpret_cast<const float4*>(ai + 4 * c4);
+              x[4 * c4] = t.x; x[4 * c4 + 1] = t.y; x[4 * c4 + 2] = t.z; x[4 * c4 + 3] = t.w;
+            }
+          } else {
+#pragma unroll
+            for (int c4 = 0; c4 < CPL / 4; ++c4) {
+              const bf16x4 t = *reinterpret_cast<const bf16x4*>(ai + 4 * c4);
+              x[4 * c4] = (float)t[0]; x[4 * c4 + 1] = (float)t[1]; x[4 * c4 + 2] = (float)t[2]; x[4 * c4 + 3] = (float)t[3];
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) a[c] *= epi_dgelu<InT>(x[c]);
+        }
+        if (p.drop_thresh) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c)
+            a[c] = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n + c), p.drop_thresh) ? a[c] * p.drop_scale : 0.f;
+        }
+        if (p.residual) {
+#pragma unroll
+          for (int c4 = 0; c4 < CPL / 4; ++c4) {
+            const float4 r = *reinterpret_cast<const float4*>(p.residual + m * p.ld_res + n + 4 * c4);
+            a[4 * c4] += r.x; a[4 * c4 + 1] += r.y; a[4 * c4 + 2] += r.z; a[4 * c4 + 3] += r.w;
+          }
+        }
+        store_vec(C + m * p.ldc + n);
+      } else {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          if (n + c >= p.N) continue;
+          float v = a[c] * p.alpha;
+          if (p.bias) v += p.bias[n + c];
+          if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n + c] = from_f32<OutT>(v);
+          if (p.act == FAVIT_ACT_GELU) v = epi_gelu<InT>(v);
+          else if (p.act == FAVIT_ACT_DGELU)
+            v *= epi_dgelu<InT>(to_f32(reinterpret_cast<const InT*>(p.aux_in)[m * p.ld_aux_in + n + c]));
+          if (p.drop_thresh) v = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n + c), p.drop_thresh) ? v * p.drop_scale : 0.f;
+          if (p.residual) v += p.residual[m * p.ld_res + n + c];
+          C[m * p.ldc + n + c] = from_f32<OutT>(v);
+        }
+      }
+    }
+  }
+}
+
+template <bool AK, bool BKM, typename OutT>
+__global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_kernel(KParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long m0 = (long)(tile / p.tiles_n) * P4_BM;
+  const long n0 = (long)(tile % p.tiles_n) * BN;
+  const int z = blockIdx.z;
+  const long zo = z / p.batch_inner, zi = z % p.batch_inner;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
+  const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
+  OutT* C = reinterpret_cast<OutT*>(p.C) + zo * p.sCo + zi * p.sCi;
+  const int nk = p.dbg == 2 ? 0 : (int)(p.K / P4_BK);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // 3 pieces per wave per stage: 2 of A (16 pieces), 1 of B (8 pieces)
+  const bf16_t* sa[2];
+  const bf16_t* sb;
+  int da[2], db;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int qa = wave * 2 + j;
+    if (AK) {
+      sa[j] = glds_src32<true>(A, p.lda, m0, p.M, 0, qa, lane);
+      da[j] = qa * 1024;
+    } else {
+      const int sub = qa >> 3, q = qa & 7;
+      sa[j] = glds_src32<false>(A, p.lda, m0 + sub * 128, p.M, 0, q, lane);
+      da[j] = sub * (P4_A_BYTES / 2) + q * 1024;
+    }
+  }
+  sb = glds_src32<BKM>(Bm, p.ldb, n0, p.N, 0, wave, lane);
+  db = P4_A_BYTES + wave * 1024;
+  auto issue = [&](int buf) {
+    char* st = smem + buf * P4_STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + da[j]), 16, 0, 0);
+      sa[j] += AK ? P4_BK : P4_BK * p.lda;
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + db), 16, 0, 0);
+    sb += BKM ? P4_BK : P4_BK * p.ldb;
+  };
+
+  // Phase stagger: the two workgroups that share a CU would otherwise run in lockstep (main loop
+  // together, epilogue together) and never overlap MFMA with the store-heavy epilogue.  The second
+  // resident set (blocks 256..511 of the launch) starts half a tile late; later blocks inherit the
+  // phase of the slot they replace.
+  if (p.stagger_ticks > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(8);
+  }
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);
+    const char* st = smem + cur * P4_STAGE;
+    const char* la = AK ? st : st + (wr >> 1) * (P4_A_BYTES / 2);
+    const int ra = AK ? wr * 64 : (wr & 1) * 64;
+    const char* lb = st + P4_A_BYTES;
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = load_frag32<AK>(la, ra + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = load_frag32<BKM>(lb, wc * 64 + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  if (p.dbg == 1) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 12345.678f) C[0] = from_f32<OutT>(s);
+    return;
+  }
+  if (p.dbg == 3) {
+    direct_epilogue<bf16_t, OutT>(p, acc, C, m0 + wr * 64, n0 + wc * 64, lane);
+    return;
+  }
+  __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
+  wave_epilogue<bf16_t, OutT>(p, acc, C, m0 + wr * 64, n0 + wc * 64, lane,
+                              reinterpret_cast<float*>(smem + wave * WEPI_BYTES));
+}
+
+template <typename Kn>
+int launch_p4(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(P4_THREADS), P4_LDS, st, kp);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
 }
 
 // --------------------------------------------------------------------------------------
@@ -594,6 +1259,8 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.atomic = atomic;
   kp.tiles_n = (int)tiles_n;
   kp.alpha = g->alpha;
+  { const char* e = getenv("FAVIT_GEMM_DBG"); kp.dbg = e ? atoi(e) : 0; }
+  { const char* e = getenv("FAVIT_GEMM_STAGGER"); kp.stagger_ticks = e ? atoi(e) : 0; }
   if (g->dropout_p < 0.f || g->dropout_p >= 1.f) return FAVIT_ERR_INVALID;
   kp.drop_thresh = dropout_threshold(g->dropout_p);
   kp.drop_scale = 1.0f / (1.0f - g->dropout_p);
@@ -624,6 +1291,67 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
 
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits, (unsigned)batch);
   const int layout = (g->a_kmajor ? 2 : 0) | (g->b_kmajor ? 1 : 0);
+  const bool glds_ok = g->in_dtype == FAVIT_BF16 && kp.a_vec && kp.b_vec && (g->K % BK16) == 0 && g->K > 0 &&
+                       (g->a_kmajor || g->M >= 8) && (g->b_kmajor || g->N >= 8) &&
+                       (g->a_kmajor || (g->M % 8) == 0) && (g->b_kmajor || (g->N % 8) == 0);
+  const bool force128 = getenv("FAVIT_GEMM_TILE128") != nullptr;
+  const bool no_p4 = getenv("FAVIT_GEMM_NO_P4") != nullptr;
+  // non-atomic, single-split, non-batched large GEMMs: the 2-workgroups-per-CU register-epilogue kernel
+  if (glds_ok && !force128 && !no_p4 && !atomic && splits == 1 && !g->a_rowsum && (g->K % P4_BK) == 0 &&
+      g->M >= 1024 && (long)((g->M + 255) / 256) * tiles_n * batch >= 256) {
+    dim3 grid4((unsigned)(((g->M + 255) / 256) * tiles_n), 1u, (unsigned)batch);
+    if (g->out_dtype == FAVIT_BF16) {
+      switch (layout) {
+        case 3: return launch_p4(gemm_bf16_p4_kernel<true, true, bf16_t>, kp, grid4, st);
+        case 2: return launch_p4(gemm_bf16_p4_kernel<true, false, bf16_t>, kp, grid4, st);
+        case 1: return launch_p4(gemm_bf16_p4_kernel<false, true, bf16_t>, kp, grid4, st);
+        default: return launch_p4(gemm_bf16_p4_kernel<false, false, bf16_t>, kp, grid4, st);
+      }
+    } else {
+      switch (layout) {
+        case 3: return launch_p4(gemm_bf16_p4_kernel<true, true, float>, kp, grid4, st);
+        case 2: return launch_p4(gemm_bf16_p4_kernel<true, false, float>, kp, grid4, st);
+        case 1: return launch_p4(gemm_bf16_p4_kernel<false, true, float>, kp, grid4, st);
+        default: return launch_p4(gemm_bf16_p4_kernel<false, false, float>, kp, grid4, st);
+      }
+    }
+  }
+  if (glds_ok && !force128 && g->M >= 1024 && (long)((g->M + 255) / 256) * tiles_n * splits * batch >= 128) {
+    KParams k3 = kp;
+    dim3 grid3((unsigned)(((g->M + 255) / 256) * tiles_n), (unsigned)splits, (unsigned)batch);
+    if (g->out_dtype == FAVIT_BF16) {
+      switch (layout) {
+        case 3: return launch_p3(gemm_bf16_p3_kernel<true, true, bf16_t>, k3, grid3, st);
+        case 2: return launch_p3(gemm_bf16_p3_kernel<true, false, bf16_t>, k3, grid3, st);
+        case 1: return launch_p3(gemm_bf16_p3_kernel<false, true, bf16_t>, k3, grid3, st);
+        default: return launch_p3(gemm_bf16_p3_kernel<false, false, bf16_t>, k3, grid3, st);
+      }
+    } else {
+      switch (layout) {
+        case 3: return launch_p3(gemm_bf16_p3_kernel<true, true, float>, k3, grid3, st);
+        case 2: return launch_p3(gemm_bf16_p3_kernel<true, false, float>, k3, grid3, st);
+        case 1: return launch_p3(gemm_bf16_p3_kernel<false, true, float>, k3, grid3, st);
+        default: return launch_p3(gemm_bf16_p3_kernel<false, false, float>, k3, grid3, st);
+      }
+    }
+  }
+  if (glds_ok) {
+    if (g->out_dtype == FAVIT_BF16) {
+      switch (layout) {
+        case 3: return launch(gemm_bf16_glds_kernel<true, true, bf16_t>, kp, grid, st);
+        case 2: return launch(gemm_bf16_glds_kernel<true, false, bf16_t>, kp, grid, st);
+        case 1: return launch(gemm_bf16_glds_kernel<false, true, bf16_t>, kp, grid, st);
+        default: return launch(gemm_bf16_glds_kernel<false, false, bf16_t>, kp, grid, st);
+      }
+    } else {
+      switch (layout) {
+        case 3: return launch(gemm_bf16_glds_kernel<true, true, float>, kp, grid, st);
+        case 2: return launch(gemm_bf16_glds_kernel<true, false, float>, kp, grid, st);
+        case 1: return launch(gemm_bf16_glds_kernel<false, true, float>, kp, grid, st);
+        default: return launch(gemm_bf16_glds_kernel<false, false, float>, kp, grid, st);
+      }
+    }
+  }
   if (g->in_dtype == FAVIT_BF16) {
     if (g->out_dtype == FAVIT_BF16) {
       switch (layout) {

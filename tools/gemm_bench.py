@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of favit_gemm on the GEMM shapes of the ViT-MHLA-Small training step
+(B=256, L=197): prints TFLOP/s per shape/layout; used under rocprofv3 --pmc for counters."""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+pkg = importlib.import_module("focused-attention-vit_amd")
+K = pkg.kernels
+dev = "cuda"
+T, D = 256 * 197, 384
+reps = int(os.environ.get("REPS", "20"))
+only = os.environ.get("ONLY")
+
+def run(name, fn, flops):
+    if only and only not in name:
+        return
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    print(f"{name:28s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
+
+bf = torch.bfloat16
+def rnd(*s, dt=bf): return torch.randn(*s, device=dev).to(dt)
+x = rnd(T, D); h = rnd(T, 4 * D)
+wqkv = rnd(3 * D, D); w1 = rnd(4 * D, D); w2 = rnd(D, 4 * D); wp = rnd(D, D)
+bq = torch.randn(3 * D, device=dev); b1 = torch.randn(4 * D, device=dev); b2 = torch.randn(D, device=dev)
+res = torch.randn(T, D, device=dev)
+o_qkv = torch.empty(T, 3 * D, device=dev, dtype=bf); o_h = torch.empty(T, 4 * D, device=dev, dtype=bf); o_pre = torch.empty_like(o_h)
+o_d = torch.empty(T, D, device=dev); o_db = torch.empty(T, D, device=dev, dtype=bf)
+dw1 = torch.empty(4 * D, D, device=dev); dw2 = torch.empty(D, 4 * D, device=dev); dwq = torch.empty(3 * D, D, device=dev)
+db = torch.zeros(4 * D, device=dev)
+A = pkg._abi
+run("fwd qkv  NT K=384 N=1152", lambda: K.gemm(x, wqkv, o_qkv, T, 3 * D, D, D, D, 3 * D, bias=bq), 2 * T * 3 * D * D)
+run("fwd fc1  NT K=384 N=1536 gelu", lambda: K.gemm(x, w1, o_h, T, 4 * D, D, D, D, 4 * D, bias=b1, act=A.ACT_GELU, aux_out=o_pre, ld_aux_out=4 * D), 2 * T * 4 * D * D)
+run("fwd fc2  NT K=1536 N=384 res", lambda: K.gemm(h, w2, o_d, T, D, 4 * D, 4 * D, 4 * D, D, bias=b2, residual=res, ld_res=D), 2 * T * 4 * D * D)
+run("fwd proj NT K=384 N=384 res", lambda: K.gemm(x, wp, o_d, T, D, D, D, D, D, bias=b2, residual=res, ld_res=D), 2 * T * D * D)
+run("bwd dX   NN K=1152 N=384", lambda: K.gemm(o_qkv, wqkv, o_db, T, D, 3 * D, 3 * D, D, D, b_kmajor=False), 2 * T * 3 * D * D)
+run("bwd dH   NN K=384 N=1536 dgelu", lambda: K.gemm(x, w2, o_h, T, 4 * D, D, D, 4 * D, 4 * D, b_kmajor=False, act=A.ACT_DGELU, aux_in=o_pre, ld_aux_in=4 * D), 2 * T * 4 * D * D)
+run("bwd dXn2 NN K=1536 N=384", lambda: K.gemm(h, w1, o_db, T, D, 4 * D, 4 * D, D, D, b_kmajor=False), 2 * T * 4 * D * D)
+run("bwd dW1  TN [1536,384]", lambda: K.gemm(h, x, dw1, 4 * D, D, T, 4 * D, D, D, a_kmajor=False, b_kmajor=False, a_rowsum=db), 2 * T * 4 * D * D)
+run("bwd dW2  TN [384,1536]", lambda: K.gemm(x, h, dw2, D, 4 * D, T, D, 4 * D, 4 * D, a_kmajor=False, b_kmajor=False, a_rowsum=db), 2 * T * 4 * D * D)
+run("bwd dWqkv TN [1152,384]", lambda: K.gemm(o_qkv, x, dwq, 3 * D, D, T, 3 * D, D, D, a_kmajor=False, b_kmajor=False, a_rowsum=db), 2 * T * 3 * D * D)
+big = 8192
+a8 = rnd(big, big); b8 = rnd(big, big); c8 = torch.empty(big, big, device=dev, dtype=bf)
+run("square 8192^3 NT", lambda: K.gemm(a8, b8, c8, big, big, big, big, big, big), 2 * big ** 3)
