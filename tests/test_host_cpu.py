@@ -1,0 +1,159 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/favit.h
+declares, the nn.Module mirrors keep the reference's constructor signatures / attribute names /
+state_dict keys / weight-init RNG order, and the product refuses to run without a GPU (there is no
+CPU fallback)."""
+import ctypes
+import importlib
+import inspect
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+MD = load_golden("models.npz")
+WIN = load_golden("windows.npz")
+
+
+def test_library_loads_and_exports_every_declared_symbol(favit):
+    lib = favit._abi.lib()
+    declared = favit._abi.declared_symbols()
+    assert len(declared) >= 25
+    for s in declared:
+        assert hasattr(lib, s), f"libfavit.so does not export {s}"
+    assert set(favit._abi._SIGS) == set(declared), "ctypes signature table out of sync with include/favit.h"
+    assert lib.favit_abi_version() == 1
+    assert lib.favit_strerror(-2).decode().startswith("unsupported")
+
+
+def test_gemm_descriptor_layout_matches_header(favit):
+    # 8 pointers + 21 int64 + 9 int32 + 3 x 4-byte + uint64, naturally aligned
+    assert ctypes.sizeof(favit._abi.GemmDesc) == 8 * 8 + 15 * 8 + 9 * 4 + 4 + 4 + 4 + 8
+    assert favit._abi.GemmDesc.dropout_seed.offset % 8 == 0
+
+
+def test_cfg2_model_init_parity_and_state_dict_keys(favit):
+    """Same RNG call order as the reference: same seed -> same weights."""
+    torch.manual_seed(1234)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384,
+                                                    depth=12, num_heads=6, window_size=7, use_mhla=True)
+    assert m.get_num_parameters() == int(MD["cfg2/n_params"]) == 22100584
+    assert list(m.state_dict().keys()) == MD["cfg2/sd_keys"].tolist()
+    assert abs(sum(p.double().sum().item() for p in m.parameters()) - float(MD["cfg2/param_sum"])) < 1e-9
+    # attribute paths the reference's experiments touch (experiments/mhla_pretrained.py:188-234)
+    assert m.patch_embed.projection[1].weight.shape == (384, 768)
+    b = m.blocks[0]
+    for path in ("norm1", "norm2", "mlp.fc1", "mlp.fc2", "attn.qkv", "attn.proj", "attn.latent_proj"):
+        obj = b
+        for part in path.split("."):
+            obj = getattr(obj, part)
+        assert isinstance(obj.weight, torch.nn.Parameter)
+    assert m.embed_dim == 384 and m.cls_token.shape == (1, 1, 384) and m.pos_embed.shape == (1, 197, 384)
+
+
+def test_cfg1_and_fallback_init_parity(favit):
+    torch.manual_seed(1234)
+    m = favit.models.vit.VisionTransformer(img_size=32, patch_size=4, num_classes=10, embed_dim=192, depth=12,
+                                           num_heads=3)
+    assert m.get_num_parameters() == int(MD["cfg1/n_params"]) == 5362762
+    assert abs(sum(p.double().sum().item() for p in m.parameters()) - float(MD["cfg1/param_sum"])) < 1e-9
+    torch.manual_seed(1234)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2,
+                                                    num_heads=4, use_mhla=False)
+    assert abs(sum(p.double().sum().item() for p in m.parameters()) - float(MD["fallback/param_sum"])) < 1e-9
+    assert "blocks.0.attn.in_proj_weight" in m.state_dict() and "blocks.0.attn.out_proj.weight" in m.state_dict()
+
+
+def test_sppp_model_has_no_pos_embed_parameter(favit):
+    m = favit.models.sppp_mhla.SPPPViTMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=1,
+                                           num_heads=4, use_mhla=True)
+    keys = list(m.state_dict().keys())
+    assert "pos_embed" not in keys and "cls_token" in keys and "patch_embed.projection.1.weight" in keys
+
+
+@pytest.mark.parametrize("cls,kw", [
+    ("vit.PatchEmbedding", dict(img_size=224, patch_size=16, in_channels=3, embed_dim=768)),
+    ("vit.MultiHeadAttention", dict(embed_dim=None, num_heads=None, dropout=0.0)),
+    ("vit.MLP", dict(in_features=None, hidden_features=None, out_features=None, dropout=0.0)),
+    ("vit.TransformerBlock", dict(embed_dim=None, num_heads=None, mlp_ratio=4.0, dropout=0.0, attn_dropout=0.0)),
+    ("mhla.MultiHeadLatentAttention", dict(embed_dim=None, num_heads=None, window_size=7, dropout=0.0)),
+    ("mhla.MHLATransformerBlock", dict(embed_dim=None, num_heads=None, window_size=7, mlp_ratio=4.0, dropout=0.0,
+                                       attn_dropout=0.0)),
+    ("vit_mhla.TransformerBlock", dict(embed_dim=None, num_heads=None, mlp_ratio=4.0, dropout=0.0, attn_dropout=0.0,
+                                       window_size=7, use_mhla=False)),
+    ("attention.CrossAttention", dict(embed_dim=None, dropout=0.0)),
+    ("attention.MultiHeadCrossAttention", dict(embed_dim=None, num_heads=None, dropout=0.0)),
+    ("attention.CrossAttentionTransformerBlock", dict(embed_dim=None, num_heads=None, mlp_ratio=4.0, dropout=0.0,
+                                                      attn_dropout=0.0, use_multi_head=False)),
+    ("sppp.DynamicPositionalEncoding", dict(embed_dim=None, dropout=0.0)),
+])
+def test_constructor_signatures_match_reference(favit, cls, kw):
+    """Parameter names, order and defaults of SURVEY 8b (None = required positional)."""
+    mod, name = cls.split(".")
+    sig = inspect.signature(getattr(getattr(favit.models, mod), name).__init__)
+    got = [(k, v.default) for k, v in list(sig.parameters.items())[1:]]
+    want = [(k, inspect.Parameter.empty if v is None else v) for k, v in kw.items()]
+    assert got == want
+
+
+def test_model_constructor_kwargs(favit):
+    names = list(inspect.signature(favit.models.vit_mhla.VisionTransformerMHLA.__init__).parameters)[1:]
+    assert names == ["img_size", "patch_size", "in_channels", "num_classes", "embed_dim", "depth", "num_heads",
+                     "mlp_ratio", "dropout", "attn_dropout", "embed_dropout", "window_size", "use_mhla"]
+    names = list(inspect.signature(favit.models.sppp_mhla.SPPPViTMHLA.__init__).parameters)[1:]
+    assert names[-5:] == ["num_superpixels", "compactness", "pooling_type", "window_size", "use_mhla"]
+
+
+def test_window_index_table_matches_reference(favit):
+    for key in WIN.files:
+        L, W = (int(s[1:]) for s in key.split("_"))
+        m = favit.models.mhla.MultiHeadLatentAttention(64, 4, window_size=W)
+        np.testing.assert_array_equal(m._get_window_indices(L).numpy(), WIN[key], err_msg=key)
+    with pytest.raises(ValueError):
+        favit.models.mhla.MultiHeadLatentAttention(64, 4, window_size=4)._get_window_indices(12)
+
+
+def test_no_cpu_fallback(favit):
+    m = favit.models.vit.MLP(16, 32, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(2, 16))
+    blk = favit.models.mhla.MHLATransformerBlock(16, 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        blk(torch.randn(1, 5, 16))
+
+
+def test_drop_in_import_as_top_level_models(tmp_path):
+    """INTEGRATION.md mode: the package directory on sys.path gives `models.vit` etc."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from models.vit_mhla import VisionTransformerMHLA; "
+            "from models.mhla import MultiHeadLatentAttention; from models.sppp_mhla import SPPPViTMHLA; "
+            "from models.attention import CrossAttentionTransformerBlock; from models.vit import VisionTransformer; "
+            "m = VisionTransformerMHLA(img_size=32, patch_size=4, embed_dim=64, depth=1, num_heads=4, use_mhla=True); "
+            "print(m.get_num_parameters())") % os.path.join(root, "focused-attention-vit_amd")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr
+    assert int(out.stdout.strip()) > 0
+
+
+def test_param_groups_follow_reference_names(favit):
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2,
+                                                    num_heads=4, use_mhla=True)
+    groups = favit.train.param_groups(m, lr=1e-4, head_lr=1e-3)
+    assert [g["lr"] for g in groups] == [1e-4, 5e-4, 1e-3]
+    assert len(groups[1]["params"]) == 2 * 2 and len(groups[2]["params"]) == 2      # latent_proj w/b per block; head w/b
+
+
+def test_flat_buffers_keep_parameter_semantics(favit):
+    lin = torch.nn.Linear(5, 3)
+    w0 = lin.weight.detach().clone()
+    flat = favit.dp.FlatBuffers(lin.parameters())
+    assert torch.equal(lin.weight, w0) and lin.weight.shape == (3, 5)
+    lin.weight.data.copy_(torch.ones(3, 5))
+    idx = next(i for i, p in enumerate(flat.params) if p is lin.weight)
+    assert flat.flat_p[flat.offsets[idx]].item() == 1.0
+    (lin(torch.ones(2, 5)).sum()).backward()
+    assert flat.flat_g.abs().sum().item() > 0
+    flat.zero_grad()
+    assert flat.flat_g.abs().sum().item() == 0 and lin.weight.grad is not None
