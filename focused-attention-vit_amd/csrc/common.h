@@ -85,6 +85,15 @@ static inline uint32_t dropout_threshold(float p) {
   return (uint32_t)t;
 }
 
+// sum over the 8 consecutive lanes of an aligned group, entirely in the VALU (DPP): quad_perm
+// [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror -- no ds_bpermute round trips through LDS.
+__device__ __forceinline__ float dpp_sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -80,12 +80,7 @@ __device__ __forceinline__ void vstore(T* p, const float (&v)[N]) {
   }
 }
 
-__device__ __forceinline__ float sum8(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  return v;
-}
+__device__ __forceinline__ float sum8(float v) { return dpp_sum8(v); }
 
 // LDS image of rows of one [*, hd] tensor: a contiguous "main" run of rows plus the head
 // rows [0, head_n) and the tail rows [tail_lo, L) that the wrap rule can reach.
@@ -382,93 +377,142 @@ __global__ __launch_bounds__(256) void mhla_bwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// latent_proj fold
+// latent_proj fold (weight space, tiny): LDS-tiled so each launch is a few microseconds.
+//   Weff[s,h] = Wl . Wqkv[s,h],  beff[s,h] = Wl . bqkv[s,h] + bl      (s in {k, v})
+// Column D of the [3D, D+1] augmented matrices is the bias.
 // ---------------------------------------------------------------------------------
+constexpr int FOLD_TC = 64;    // columns per workgroup
+
+// grid (ceil((D+1)/64), 2H + 1): blockIdx.y < 2H -> one (s,h) block of hd rows; == 2H -> the q rows (copy)
 template <typename T>
-__global__ void fold_fwd_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqkv,
-                                const float* __restrict__ wl, const float* __restrict__ bl, T* __restrict__ weff,
-                                float* __restrict__ weff_f32, float* __restrict__ beff, int D, int hd) {
-  // one thread per (row r of [3D], column c of [D+1]); column D is the bias
-  const long total = 3L * D * (D + 1);
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int r = (int)(t / (D + 1)), c = (int)(t % (D + 1));
-    float v;
-    if (r < D) {
-      v = (c < D) ? wqkv[(long)r * D + c] : bqkv[r];
-    } else {
-      const int i = r % hd, base = r - i;
-      float acc = 0.f;
+__global__ __launch_bounds__(256) void fold_fwd_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqkv,
+                                                       const float* __restrict__ wl, const float* __restrict__ bl,
+                                                       T* __restrict__ weff, float* __restrict__ weff_f32,
+                                                       float* __restrict__ beff, int D, int hd, int H) {
+  extern __shared__ float sh[];            // Wl [hd][hd] + W tile [hd][64]
+  const int tc = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = blockIdx.x * FOLD_TC + tc;            // column of the augmented matrix (D = bias)
+  if ((int)blockIdx.y == 2 * H) {                      // q part: plain copy / cast
+    if (c > D) return;
+    for (int r = tg; r < D; r += 4) {
+      const float v = (c < D) ? wqkv[(long)r * D + c] : bqkv[r];
       if (c < D) {
-        for (int j = 0; j < hd; ++j) acc = fmaf(wl[i * hd + j], wqkv[(long)(base + j) * D + c], acc);
+        weff[(long)r * D + c] = from_f32<T>(v);
+        if (weff_f32) weff_f32[(long)r * D + c] = v;
       } else {
-        for (int j = 0; j < hd; ++j) acc = fmaf(wl[i * hd + j], bqkv[base + j], acc);
-        acc += bl[i];
+        beff[r] = v;
       }
-      v = acc;
     }
+    return;
+  }
+  float* swl = sh;
+  float* sw = sh + hd * hd;
+  const long base = (long)D + (long)blockIdx.y * hd;   // first row of this (s,h) block
+  for (int i = threadIdx.x; i < hd * hd; i += 256) swl[i] = wl[i];
+  for (int j = tg; j < hd; j += 4) sw[j * FOLD_TC + tc] = (c < D) ? wqkv[(base + j) * D + c] : (c == D ? bqkv[base + j] : 0.f);
+  __syncthreads();
+  if (c > D) return;
+  for (int i = tg; i < hd; i += 4) {
+    float acc = 0.f;
+    for (int j = 0; j < hd; ++j) acc = fmaf(swl[i * hd + j], sw[j * FOLD_TC + tc], acc);
+    const long r = base + i;
     if (c < D) {
-      weff[(long)r * D + c] = from_f32<T>(v);
-      if (weff_f32) weff_f32[(long)r * D + c] = v;
+      weff[r * D + c] = from_f32<T>(acc);
+      if (weff_f32) weff_f32[r * D + c] = acc;
     } else {
-      beff[r] = v;
+      beff[r] = acc + bl[i];
     }
   }
 }
 
-__global__ void fold_bwd_w_kernel(const float* __restrict__ dweff, const float* __restrict__ dbeff,
-                                  const float* __restrict__ wl, float* __restrict__ dwqkv, float* __restrict__ dbqkv,
-                                  int D, int hd) {
-  const long total = 3L * D * (D + 1);
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int r = (int)(t / (D + 1)), c = (int)(t % (D + 1));
-    float v;
-    if (r < D) {
-      v = (c < D) ? dweff[(long)r * D + c] : dbeff[r];
-    } else {
-      const int j = r % hd, base = r - j;
-      float acc = 0.f;
-      if (c < D) {
-        for (int i = 0; i < hd; ++i) acc = fmaf(wl[i * hd + j], dweff[(long)(base + i) * D + c], acc);
-      } else {
-        for (int i = 0; i < hd; ++i) acc = fmaf(wl[i * hd + j], dbeff[base + i], acc);
-      }
-      v = acc;
-    }
-    if (c < D) dwqkv[(long)r * D + c] = v;
-    else dbqkv[r] = v;
+// dWqkv[s,h] = Wl^T . dWeff[s,h] (and the bias column); q rows are copied.  Same grid as fold_fwd.
+__global__ __launch_bounds__(256) void fold_bwd_w_kernel(const float* __restrict__ dweff, const float* __restrict__ dbeff,
+                                                         const float* __restrict__ wl, float* __restrict__ dwqkv,
+                                                         float* __restrict__ dbqkv, int D, int hd, int H,
+                                                         int accumulate) {
+  extern __shared__ float sh[];
+  const int tc = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const int c = blockIdx.x * FOLD_TC + tc;
+  auto put = [&](long r, float v) {
+    if (c < D) dwqkv[r * D + c] = accumulate ? dwqkv[r * D + c] + v : v;
+    else dbqkv[r] = accumulate ? dbqkv[r] + v : v;
+  };
+  if ((int)blockIdx.y == 2 * H) {
+    if (c > D) return;
+    for (int r = tg; r < D; r += 4) put(r, (c < D) ? dweff[(long)r * D + c] : dbeff[r]);
+    return;
+  }
+  float* swl = sh;
+  float* sw = sh + hd * hd;
+  const long base = (long)D + (long)blockIdx.y * hd;
+  for (int i = threadIdx.x; i < hd * hd; i += 256) swl[i] = wl[i];
+  for (int i = tg; i < hd; i += 4) sw[i * FOLD_TC + tc] = (c < D) ? dweff[(base + i) * D + c] : (c == D ? dbeff[base + i] : 0.f);
+  __syncthreads();
+  if (c > D) return;
+  for (int j = tg; j < hd; j += 4) {
+    float acc = 0.f;
+    for (int i = 0; i < hd; ++i) acc = fmaf(swl[i * hd + j], sw[i * FOLD_TC + tc], acc);
+    put(base + j, acc);
   }
 }
 
-// dWl[i][j] = sum_z ( dWeff_z[i,:] . Wqkv_z[j,:] + dbeff_z[i] * bqkv_z[j] ), dbl[i] = sum_z dbeff_z[i]
-// grid (hd, 2H): block (i, z) produces one partial row of dWl and adds it atomically.
+// dWl[i][j] += sum_c dWeff_z[i][c] Wqkv_z[j][c] + dbeff_z[i] bqkv_z[j];  dbl[i] += dbeff_z[i].
+// grid (2H): one workgroup per (s,h) block z walks the D columns in tiles of 64 and adds its
+// [hd, hd] partial with fp32 atomics (2H-way contention only).
+template <int HD>
 __global__ __launch_bounds__(256) void fold_bwd_l_kernel(const float* __restrict__ dweff,
                                                          const float* __restrict__ dbeff,
                                                          const float* __restrict__ wqkv,
                                                          const float* __restrict__ bqkv, float* __restrict__ dwl,
-                                                         float* __restrict__ dbl, int D, int hd) {
-  extern __shared__ float sh[];       // dWeff row [D] + partials [4][hd]
-  float* rowbuf = sh;
-  float* part = sh + D;
-  const int i = blockIdx.x, z = blockIdx.y;
-  const long base = (long)D + (long)z * hd;      // first row of this (s,h) block
-  for (int c = threadIdx.x; c < D; c += 256) rowbuf[c] = dweff[(base + i) * D + c];
-  __syncthreads();
-  const int nq = 256 / hd > 0 ? 256 / hd : 1;    // column splits per j (hd <= 256)
-  const int j = threadIdx.x % hd, qd = threadIdx.x / hd;
-  float acc = 0.f;
-  if (qd < nq) {
-    const float* wr = wqkv + (base + j) * D;
-    for (int c = qd; c < D; c += nq) acc = fmaf(rowbuf[c], wr[c], acc);
-    if (qd == 0) acc = fmaf(dbeff[base + i], bqkv[base + j], acc);
-    part[qd * hd + j] = acc;
+                                                         float* __restrict__ dbl, int D) {
+  extern __shared__ float sh[];            // A tile [HD][65] (dWeff), B tile [HD][65] (Wqkv)
+  float* sa = sh;
+  float* sb = sh + HD * 65;
+  const int tc = threadIdx.x & 63, tg = threadIdx.x >> 6;
+  const long base = (long)D + (long)blockIdx.x * HD;
+  constexpr int NJ = (HD + 63) / 64, NI = (HD + 3) / 4;
+  float acc[NI][NJ];
+#pragma unroll
+  for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) acc[ii][jj] = 0.f;
+  for (int c0 = 0; c0 <= D; c0 += 64) {            // column D = bias column
+    __syncthreads();
+    for (int r = tg; r < HD; r += 4) {
+      const int c = c0 + tc;
+      sa[r * 65 + tc] = (c < D) ? dweff[(base + r) * D + c] : (c == D ? dbeff[base + r] : 0.f);
+      sb[r * 65 + tc] = (c < D) ? wqkv[(base + r) * D + c] : (c == D ? bqkv[base + r] : 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int j = tc + 64 * jj;
+      if (j < HD) {
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii) {
+          const int i = tg + 4 * ii;
+          if (i < HD) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) s = fmaf(sa[i * 65 + k], sb[j * 65 + k], s);
+            acc[ii][jj] += s;
+          }
+        }
+      }
+    }
   }
-  __syncthreads();
-  if (threadIdx.x < hd) {
-    float s = 0.f;
-    for (int q = 0; q < nq; ++q) s += part[q * hd + threadIdx.x];
-    atomicAdd(dwl + (long)i * hd + threadIdx.x, s);
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int j = tc + 64 * jj;
+    if (j < HD) {
+#pragma unroll
+      for (int ii = 0; ii < NI; ++ii) {
+        const int i = tg + 4 * ii;
+        if (i < HD) atomicAdd(dwl + (long)i * HD + j, acc[ii][jj]);
+      }
+    }
   }
-  if (threadIdx.x == 0) atomicAdd(dbl + i, dbeff[base + i]);
+  if (threadIdx.x < HD) atomicAdd(dbl + threadIdx.x, dbeff[base + threadIdx.x]);
 }
 
 template <typename T, int DPL, int WMAX>
@@ -543,13 +587,14 @@ extern "C" int favit_mhla_fold_fwd(const float* wqkv, const float* bqkv, const f
                                    int weff_dtype, float* weff_f32, float* beff, int32_t D, int32_t H, void* stream) {
   if (!wqkv || !bqkv || !wl || !bl || !weff || !beff || D <= 0 || H <= 0 || D % H) return FAVIT_ERR_INVALID;
   const int hd = D / H;
-  const long total = 3L * D * (D + 1);
-  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (hd > 128) return FAVIT_ERR_UNSUPPORTED;
+  const dim3 grid((D + 1 + FOLD_TC - 1) / FOLD_TC, 2 * H + 1);
+  const size_t lds = sizeof(float) * ((size_t)hd * hd + (size_t)hd * FOLD_TC);
   hipStream_t st = as_stream(stream);
   if (weff_dtype == FAVIT_F32)
-    hipLaunchKernelGGL((fold_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, wqkv, bqkv, wl, bl, (float*)weff, weff_f32, beff, D, hd);
+    hipLaunchKernelGGL((fold_fwd_kernel<float>), grid, dim3(256), lds, st, wqkv, bqkv, wl, bl, (float*)weff, weff_f32, beff, D, hd, H);
   else if (weff_dtype == FAVIT_BF16)
-    hipLaunchKernelGGL((fold_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, wqkv, bqkv, wl, bl, (bf16_t*)weff, weff_f32, beff, D, hd);
+    hipLaunchKernelGGL((fold_fwd_kernel<bf16_t>), grid, dim3(256), lds, st, wqkv, bqkv, wl, bl, (bf16_t*)weff, weff_f32, beff, D, hd, H);
   else
     return FAVIT_ERR_INVALID;
   FAVIT_CHECK_LAUNCH();
@@ -558,21 +603,28 @@ extern "C" int favit_mhla_fold_fwd(const float* wqkv, const float* bqkv, const f
 
 extern "C" int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const float* wqkv, const float* bqkv,
                                    const float* wl, float* dwqkv, float* dbqkv, float* dwl, float* dbl, int32_t D,
-                                   int32_t H, void* stream) {
+                                   int32_t H, int32_t accumulate, void* stream) {
   if (!dweff || !dbeff || !wqkv || !bqkv || !wl || !dwqkv || !dbqkv || !dwl || !dbl || D <= 0 || H <= 0 || D % H)
     return FAVIT_ERR_INVALID;
   const int hd = D / H;
-  if (hd > 256) return FAVIT_ERR_UNSUPPORTED;
+  if (hd > 128) return FAVIT_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
-  const long total = 3L * D * (D + 1);
-  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(fold_bwd_w_kernel, dim3(grid), dim3(256), 0, st, dweff, dbeff, wl, dwqkv, dbqkv, D, hd);
+  const dim3 grid((D + 1 + FOLD_TC - 1) / FOLD_TC, 2 * H + 1);
+  const size_t lds_w = sizeof(float) * ((size_t)hd * hd + (size_t)hd * FOLD_TC);
+  hipLaunchKernelGGL(fold_bwd_w_kernel, grid, dim3(256), lds_w, st, dweff, dbeff, wl, dwqkv, dbqkv, D, hd, H, accumulate);
   FAVIT_CHECK_LAUNCH();
-  (void)hipMemsetAsync(dwl, 0, sizeof(float) * hd * hd, st);
-  (void)hipMemsetAsync(dbl, 0, sizeof(float) * hd, st);
-  const int nq = 256 / hd > 0 ? 256 / hd : 1;
-  const size_t lds = sizeof(float) * ((size_t)D + (size_t)nq * hd);
-  hipLaunchKernelGGL(fold_bwd_l_kernel, dim3(hd, 2 * H), dim3(256), lds, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D, hd);
+  if (!accumulate) {
+    (void)hipMemsetAsync(dwl, 0, sizeof(float) * hd * hd, st);
+    (void)hipMemsetAsync(dbl, 0, sizeof(float) * hd, st);
+  }
+  const size_t lds = sizeof(float) * (size_t)2 * hd * 65;
+  switch (hd) {
+    case 16: hipLaunchKernelGGL(fold_bwd_l_kernel<16>, dim3(2 * H), dim3(256), lds, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
+    case 32: hipLaunchKernelGGL(fold_bwd_l_kernel<32>, dim3(2 * H), dim3(256), lds, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
+    case 64: hipLaunchKernelGGL(fold_bwd_l_kernel<64>, dim3(2 * H), dim3(256), lds, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
+    case 128: hipLaunchKernelGGL(fold_bwd_l_kernel<128>, dim3(2 * H), dim3(256), lds, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
+    default: return FAVIT_ERR_UNSUPPORTED;
+  }
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }

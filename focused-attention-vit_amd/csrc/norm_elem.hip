@@ -150,20 +150,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy,
   }
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ in, long ld, float* __restrict__ out, long rows, int cols,
-                                   int accumulate) {
-  // block = 64 columns x 4 row groups
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ in, long ld,
+                                                            float* __restrict__ out, float* __restrict__ out1,
+                                                            long rows, int cols, int accumulate) {
+  // block = 64 columns x 16 row groups; blockIdx.y = 1 selects the second stacked matrix -> out1
+  __shared__ float red[16][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cx;
+  const float* src = in + (long)blockIdx.y * rows * ld;
+  float* dst = blockIdx.y ? out1 : out;
   float s = 0.f;
   if (col < cols)
-    for (long r = ry; r < rows; r += 4) s += in[r * ld + col];
+    for (long r = ry; r < rows; r += 16) s += src[r * ld + col];
   red[ry][cx] = s;
   __syncthreads();
   if (ry == 0 && col < cols) {
-    const float t = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
-    out[col] = accumulate ? out[col] + t : t;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cx];
+    dst[col] = accumulate ? dst[col] + t : t;
   }
 }
 
@@ -336,10 +341,12 @@ extern "C" int favit_layernorm_fwd(const float* x, int64_t ldx, const float* gam
 extern "C" int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x, int64_t ldx, const float* gamma,
                                    const float* mean, const float* rstd, const float* dres, float* dx, int64_t lddx,
                                    void* dx_lp, int lp_dtype, float* dgamma_part, float* dbeta_part, int32_t nparts,
-                                   int64_t rows, int32_t D, void* stream) {
+                                   float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t D,
+                                   void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_part || !dbeta_part || rows <= 0 || D <= 0 ||
       nparts <= 0)
     return FAVIT_ERR_INVALID;
+  if (dbeta_part != dgamma_part + (long)nparts * D) return FAVIT_ERR_INVALID;   // [2][nparts][D] workspace
   if ((D & 3) || (ldx & 3) || (lddx & 3)) return FAVIT_ERR_ALIGN;
   if (dy_dtype != lp_dtype && dx_lp) return FAVIT_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
@@ -356,14 +363,19 @@ extern "C" int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x,
   LN_DISPATCH_NV(D, LN_BWD);
 #undef LN_BWD
   FAVIT_CHECK_LAUNCH();
+  if (dgamma && dbeta) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 63) / 64, 2), dim3(1024), 0, st, dgamma_part, (long)D, dgamma,
+                       dbeta, (long)nparts, D, accumulate);
+    FAVIT_CHECK_LAUNCH();
+  }
   return FAVIT_OK;
 }
 
 extern "C" int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_t rows, int32_t cols,
                                  int32_t accumulate, void* stream) {
   if (!in || !out || rows <= 0 || cols <= 0) return FAVIT_ERR_INVALID;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 63) / 64), dim3(256), 0, as_stream(stream), in, (long)ld, out,
-                     (long)rows, cols, accumulate);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 63) / 64, 1), dim3(1024), 0, as_stream(stream), in, (long)ld, out,
+                     (float*)nullptr, (long)rows, cols, accumulate);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }

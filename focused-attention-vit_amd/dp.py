@@ -82,10 +82,18 @@ class GradSync:
         self._handles = []
         self._launched = [False] * len(self.buckets)
         self._hooks = []
+        self._index = {id(p): i for i, p in enumerate(flat.params)}
         if self.world > 1:
             for i, p in enumerate(flat.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
+
+    def grad_ready(self, p):
+        """Called by the kernels' direct gradient-accumulation path (functional.set_grad_ready_hook)
+        for parameters autograd never sees a gradient for."""
+        i = self._index.get(id(p))
+        if i is not None and self.world > 1:
+            self._make_hook(i)(p)
 
     def _make_hook(self, i):
         def hook(_p):

@@ -23,7 +23,38 @@ from ._abi import ACT_DGELU, ACT_GELU, ACT_NONE
 # ------------------------------------------------------------------------------------
 # configuration
 # ------------------------------------------------------------------------------------
-_STATE = {"cdt": torch.float32, "epoch": 0}
+_STATE = {"cdt": torch.float32, "epoch": 0, "direct_grads": True, "grad_ready": None}
+
+
+def set_direct_grads(on: bool) -> None:
+    """When on (default), parameter gradients are accumulated by the kernels straight into an
+    existing fp32 ``param.grad`` buffer (split-K atomics / fused reductions write there anyway),
+    and autograd gets ``None`` for those parameters: no temporary gradient tensors, no zero-fill,
+    no ``grad += g`` pass.  Parameters without a ``.grad`` buffer get ordinary returned grads."""
+    _STATE["direct_grads"] = bool(on)
+
+
+def set_grad_ready_hook(fn) -> None:
+    """fn(param) is called after a parameter's gradient was accumulated directly (dp.GradSync)."""
+    _STATE["grad_ready"] = fn
+
+
+def _gt(p):
+    """The gradient buffer of parameter p that kernels may accumulate into, or None."""
+    if p is None or not _STATE["direct_grads"] or not getattr(p, "requires_grad", False):
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or not g.is_cuda:
+        return None
+    return g
+
+
+def _ready(*params):
+    fn = _STATE["grad_ready"]
+    if fn is not None:
+        for p in params:
+            if p is not None:
+                fn(p)
 
 
 def set_compute_dtype(d) -> None:
@@ -104,12 +135,22 @@ def lin_bwd_x(dy, w_c, M, N, Kd, out_dtype, *, dgelu_pre=None, drop=(0.0, 0)):
     return dx
 
 
-def lin_bwd_w(dy, a, M, N, Kd, want_bias=True):
-    """dw[N,K] = dy[M,N]^T @ a[M,K] (fp32, split-K over the tokens), db[N] = column sums of dy (fused)."""
-    dw = torch.empty((N, Kd), dtype=torch.float32, device=dy.device)
-    db = torch.zeros(N, dtype=torch.float32, device=dy.device) if want_bias else None
-    K.gemm(dy, a, dw, N, Kd, M, N, Kd, Kd, a_kmajor=False, b_kmajor=False, a_rowsum=db)
-    return dw, db
+def lin_bwd_w(dy, a, M, N, Kd, want_bias=True, wp=None, bp=None):
+    """dw[N,K] = dy[M,N]^T @ a[M,K] (fp32, split-K over the tokens), db[N] = column sums of dy (fused).
+    If the parameters wp / bp own usable .grad buffers the results are accumulated there and None
+    is returned in their place."""
+    tw = _gt(wp)
+    tb = _gt(bp) if want_bias else None
+    dw = tw if tw is not None else torch.empty((N, Kd), dtype=torch.float32, device=dy.device)
+    db = None
+    if want_bias:
+        db = tb if tb is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
+    K.gemm(dy, a, dw, N, Kd, M, N, Kd, Kd, a_kmajor=False, b_kmajor=False, a_rowsum=db, accumulate=tw is not None)
+    if tw is not None:
+        _ready(wp)
+    if tb is not None:
+        _ready(bp)
+    return (None if tw is not None else dw), (None if tb is not None else db)
 
 
 # ------------------------------------------------------------------------------------
@@ -177,7 +218,7 @@ class MHLAChain:
         pp = self.p_proj if training else 0.0
         sa = _seed() if pa > 0 else 0
         sp = _seed() if pp > 0 else 0
-        weff, beff = K.mhla_fold_fwd(wqkv.detach(), bqkv.detach(), wl.detach(), bl.detach(), H, xn.dtype)
+        weff, beff = K.mhla_fold_fwd(wqkv, bqkv, wl, bl, H, xn.dtype)
         qkv = lin_fwd(xn, weff, beff, M, 3 * D, D, xn.dtype)
         o = K.mhla_attn_fwd(qkv, B, L, H, hd, self.W, mask, pa, sa)
         wp_c = wcast(wp)
@@ -191,11 +232,16 @@ class MHLAChain:
         H, hd = self.H, D // self.H
         dym = K.dropout(dy_lp, pp, sp) if pp > 0 else dy_lp
         do = lin_bwd_x(dym, wp_c, M, D, D, xn.dtype)
-        dwp, dbp = lin_bwd_w(dym, o, M, D, D)
+        dwp, dbp = lin_bwd_w(dym, o, M, D, D, wp=wp, bp=bp)
         dqkv = K.mhla_attn_bwd(qkv, do, B, L, H, hd, self.W, mask, pa, sa)
         dxn = lin_bwd_x(dqkv, weff, M, 3 * D, D, xn.dtype)
         dweff, dbeff = lin_bwd_w(dqkv, xn, M, 3 * D, D)
-        dwqkv, dbqkv, dwl, dbl = K.mhla_fold_bwd(dweff, dbeff, wqkv.detach(), bqkv.detach(), wl.detach(), H)
+        tg = [_gt(p) for p in (wqkv, bqkv, wl, bl)]
+        if all(t is not None for t in tg):
+            K.mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H, out=tg)
+            _ready(wqkv, bqkv, wl, bl)
+            return dxn, [None, None, None, None, dwp, dbp]
+        dwqkv, dbqkv, dwl, dbl = K.mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H)
         return dxn, [dwqkv, dbqkv, dwl, dbl, dwp, dbp]
 
 
@@ -228,21 +274,22 @@ class DenseChain:
         ov = _View(o, 0, D, L * D, hd)
         P, Pd = sdpa_fwd(q, k, v, ov, B, H, L, L, hd, hd ** -0.5, mask, L if mask is not None else 0, 0, pa, sa)
         y = lin_fwd(o, wp_c, bp.detach(), M, D, D, torch.float32, residual=residual, drop=(pp, sp))
-        return y, (xn, wqkv_c, qkv, o, wp_c, P, Pd, B, L, pa, sa, pp, sp)
+        return y, (xn, wqkv_c, qkv, o, wp_c, P, Pd, B, L, pa, sa, pp, sp, prm)
 
     def bwd(self, saved, dy_lp):
-        xn, wqkv_c, qkv, o, wp_c, P, Pd, B, L, pa, sa, pp, sp = saved
+        xn, wqkv_c, qkv, o, wp_c, P, Pd, B, L, pa, sa, pp, sp, prm = saved
+        wqkv, bqkv, wp, bp = prm
         M, D = xn.shape
         H, hd = self.H, D // self.H
         dym = K.dropout(dy_lp, pp, sp) if pp > 0 else dy_lp
         do = lin_bwd_x(dym, wp_c, M, D, D, xn.dtype)
-        dwp, dbp = lin_bwd_w(dym, o, M, D, D)
+        dwp, dbp = lin_bwd_w(dym, o, M, D, D, wp=wp, bp=bp)
         dqkv = torch.empty_like(qkv)
         q, k, v = self._views(qkv, B, L, D, hd)
         dq, dk, dv = self._views(dqkv, B, L, D, hd)
         sdpa_bwd(q, k, v, _View(do, 0, D, L * D, hd), dq, dk, dv, P, Pd, B, H, L, L, hd, hd ** -0.5, pa, sa)
         dxn = lin_bwd_x(dqkv, wqkv_c, M, 3 * D, D, xn.dtype)
-        dwqkv, dbqkv = lin_bwd_w(dqkv, xn, M, 3 * D, D)
+        dwqkv, dbqkv = lin_bwd_w(dqkv, xn, M, 3 * D, D, wp=wqkv, bp=bqkv)
         return dxn, [dwqkv, dbqkv, dwp, dbp]
 
 
@@ -272,27 +319,28 @@ class CrossChain:
                          _View(o, 0, D, Lq * D, hd), B, H, Lq, Lk, hd, scale, mask,
                          Lq * Lk if mask is not None else 0, Lk if mask is not None else 0, pa, sa)
         y = lin_fwd(o, wo_c, bo.detach(), B * Lq, D, D, torch.float32, residual=residual)
-        return y, (qn, kn, q, k, v, o, (wq_c, wk_c, wv_c, wo_c), P, Pd, B, Lq, Lk, pa, sa, scale)
+        return y, (qn, kn, q, k, v, o, (wq_c, wk_c, wv_c, wo_c), P, Pd, B, Lq, Lk, pa, sa, scale, prm)
 
     def bwd(self, saved, dy_lp):
-        qn, kn, q, k, v, o, (wq_c, wk_c, wv_c, wo_c), P, Pd, B, Lq, Lk, pa, sa, scale = saved
+        qn, kn, q, k, v, o, (wq_c, wk_c, wv_c, wo_c), P, Pd, B, Lq, Lk, pa, sa, scale, prm = saved
+        wq, bq, wk, bk, wv, bv, wo, bo = prm
         D = qn.shape[1]
         H, hd = self.H, D // self.H
         cdt = qn.dtype
         Mq, Mk = B * Lq, B * Lk
         do = lin_bwd_x(dy_lp, wo_c, Mq, D, D, cdt)
-        dwo, dbo = lin_bwd_w(dy_lp, o, Mq, D, D)
+        dwo, dbo = lin_bwd_w(dy_lp, o, Mq, D, D, wp=wo, bp=bo)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         sdpa_bwd(_View(q, 0, D, Lq * D, hd), _View(k, 0, D, Lk * D, hd), _View(v, 0, D, Lk * D, hd),
                  _View(do, 0, D, Lq * D, hd), _View(dq, 0, D, Lq * D, hd), _View(dk, 0, D, Lk * D, hd),
                  _View(dv, 0, D, Lk * D, hd), P, Pd, B, H, Lq, Lk, hd, scale, pa, sa)
         dqn = lin_bwd_x(dq, wq_c, Mq, D, D, cdt)
-        dwq, dbq = lin_bwd_w(dq, qn, Mq, D, D)
+        dwq, dbq = lin_bwd_w(dq, qn, Mq, D, D, wp=wq, bp=bq)
         dkn = torch.empty((Mk, D), dtype=torch.float32, device=qn.device)
         K.gemm(dk, wk_c, dkn, Mk, D, D, D, D, D, b_kmajor=False)
         K.gemm(dv, wv_c, dkn, Mk, D, D, D, D, D, b_kmajor=False, accumulate=True)
-        dwk, dbk = lin_bwd_w(dk, kn, Mk, D, D)
-        dwv, dbv = lin_bwd_w(dv, kn, Mk, D, D)
+        dwk, dbk = lin_bwd_w(dk, kn, Mk, D, D, wp=wk, bp=bk)
+        dwv, dbv = lin_bwd_w(dv, kn, Mk, D, D, wp=wv, bp=bv)
         return dqn, dkn, [dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo]
 
 
@@ -314,17 +362,18 @@ class MLPChain:
         w1_c, w2_c = wcast(w1), wcast(w2)
         h, pre = lin_fwd(xn, w1_c, b1.detach(), M, Hd, D, xn.dtype, act=ACT_GELU, want_pre=True, drop=(p, s1))
         y = lin_fwd(h, w2_c, b2.detach(), M, Do, Hd, torch.float32, residual=residual, drop=(p, s2))
-        return y, (xn, pre, h, w1_c, w2_c, p, s1, s2)
+        return y, (xn, pre, h, w1_c, w2_c, p, s1, s2, prm)
 
     def bwd(self, saved, dy_lp):
-        xn, pre, h, w1_c, w2_c, p, s1, s2 = saved
+        xn, pre, h, w1_c, w2_c, p, s1, s2, prm = saved
+        w1, b1, w2, b2 = prm
         M, D = xn.shape
         Hd, Do = w1_c.shape[0], w2_c.shape[0]
         dym = K.dropout(dy_lp, p, s2) if p > 0 else dy_lp
         dpre = lin_bwd_x(dym, w2_c, M, Do, Hd, xn.dtype, dgelu_pre=pre, drop=(p, s1))
-        dw2, db2 = lin_bwd_w(dym, h, M, Do, Hd)
+        dw2, db2 = lin_bwd_w(dym, h, M, Do, Hd, wp=w2, bp=b2)
         dxn = lin_bwd_x(dpre, w1_c, M, Hd, D, xn.dtype)
-        dw1, db1 = lin_bwd_w(dpre, xn, M, Hd, D)
+        dw1, db1 = lin_bwd_w(dpre, xn, M, Hd, D, wp=w1, bp=b1)
         return dxn, [dw1, db1, dw2, db2]
 
 
@@ -366,14 +415,14 @@ class LinearOp:
         w_c = wcast(w)
         M, Kd, N = a.shape[0], a.shape[1], w.shape[0]
         y = lin_fwd(a, w_c, None if b is None else b.detach(), M, N, Kd, torch.float32)
-        return y.reshape(*shp[:-1], N), (a, w_c, shp, b is not None)
+        return y.reshape(*shp[:-1], N), (a, w_c, shp, b is not None, (w, b))
 
     def bwd(self, saved, dy, needs):
-        a, w_c, shp, has_b = saved
+        a, w_c, shp, has_b, (w, b) = saved
         M, Kd, N = a.shape[0], a.shape[1], w_c.shape[0]
         dy_c = _as_cdt(dy.reshape(M, N))
         dx = lin_bwd_x(dy_c, w_c, M, N, Kd, torch.float32).reshape(shp) if needs[0] else None
-        dw, db = lin_bwd_w(dy_c, a, M, N, Kd, want_bias=has_b)
+        dw, db = lin_bwd_w(dy_c, a, M, N, Kd, want_bias=has_b, wp=w, bp=b)
         return [dx], [dw, db] if has_b else [dw]
 
 
@@ -391,14 +440,14 @@ class PatchEmbedOp:
         D = w.shape[0]
         w_c = wcast(w)
         tok = lin_fwd(patches, w_c, b.detach(), M, D, Kd, torch.float32)
-        return tok.reshape(B, M // B, D), (patches, w_c, (B, Cc, HW))
+        return tok.reshape(B, M // B, D), (patches, w_c, (B, Cc, HW), (w, b))
 
     def bwd(self, saved, dy, needs):
-        patches, w_c, (B, Cc, HW) = saved
+        patches, w_c, (B, Cc, HW), (w, b) = saved
         M, Kd = patches.shape
         D = w_c.shape[0]
         dy_c = _as_cdt(dy.reshape(M, D))
-        dw, db = lin_bwd_w(dy_c, patches, M, D, Kd)
+        dw, db = lin_bwd_w(dy_c, patches, M, D, Kd, wp=w if w.is_leaf else None, bp=b)
         dimg = None
         if needs[0]:
             dpatch = lin_bwd_x(dy_c, w_c, M, D, Kd, torch.float32)
@@ -457,7 +506,7 @@ class EncoderOp:
         tapes = []
         off = 0
         for bs in self.blocks:
-            p = [t.detach() for t in prm[off:off + bs.n]]
+            p = list(prm[off:off + bs.n])
             off += bs.n
             na = len(bs.attn.names)
             g1, b1 = p[0], p[1]
@@ -468,7 +517,7 @@ class EncoderOp:
             x1, sa = bs.attn.fwd(xn1, pa, B, L, x, self.mask, self.training)
             xn2, mu2, rs2 = K.layernorm_fwd(x1, D, g2, b2, M, D, cdt)
             x2, sm = bs.mlp.fwd(xn2, pm, x1, self.training)
-            tapes.append((x, mu1, rs1, g1, sa, x1, mu2, rs2, g2, sm))
+            tapes.append((x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm))
             x = x2
         return x.reshape(B, L, D), (tapes, B, L, D)
 
@@ -479,11 +528,17 @@ class EncoderOp:
         g_lp = _as_cdt(g)
         grads = []
         for bs, tp in zip(reversed(self.blocks), reversed(tapes)):
-            x, mu1, rs1, g1, sa, x1, mu2, rs2, g2, sm = tp
+            x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm = tp
             dxn2, gm = bs.mlp.bwd(sm, g_lp)
-            g, g_lp, dg2, db2 = K.layernorm_bwd(dxn2, x1, D, g2, mu2, rs2, M, D, dres=g, want_lp=True)
+            g, g_lp, dg2, db2 = K.layernorm_bwd(dxn2, x1, D, g2, mu2, rs2, M, D, dres=g, want_lp=True,
+                                                dg_out=_gt(g2), db_out=_gt(b2))
+            if dg2 is None:
+                _ready(g2, b2)
             dxn1, ga = bs.attn.bwd(sa, g_lp)
-            g, g_lp, dg1, db1 = K.layernorm_bwd(dxn1, x, D, g1, mu1, rs1, M, D, dres=g, want_lp=True)
+            g, g_lp, dg1, db1 = K.layernorm_bwd(dxn1, x, D, g1, mu1, rs1, M, D, dres=g, want_lp=True,
+                                                dg_out=_gt(g1), db_out=_gt(b1))
+            if dg1 is None:
+                _ready(g1, b1)
             grads = [dg1, db1] + ga + [dg2, db2] + gm + grads
         return [g.reshape(B, L, D)], grads
 
@@ -495,13 +550,15 @@ class FinalNormOp:
         (x,), (g, b) = ins, prm
         B, L, D = x.shape
         x = _as_f32(x)
-        y, mu, rs = K.layernorm_fwd(x, L * D, g.detach(), b.detach(), B, D, torch.float32)
-        return y, (x, mu, rs, g.detach(), (B, L, D))
+        y, mu, rs = K.layernorm_fwd(x, L * D, g, b, B, D, torch.float32)
+        return y, (x, mu, rs, (g, b), (B, L, D))
 
     def bwd(self, saved, dy, needs):
-        x, mu, rs, g, (B, L, D) = saved
+        x, mu, rs, (g, b), (B, L, D) = saved
         dx = torch.zeros((B, L, D), dtype=torch.float32, device=x.device)
-        _, _, dg, db = K.layernorm_bwd(dy, x, L * D, g, mu, rs, B, D, dx=dx, lddx=L * D)
+        _, _, dg, db = K.layernorm_bwd(dy, x, L * D, g, mu, rs, B, D, dx=dx, lddx=L * D, dg_out=_gt(g), db_out=_gt(b))
+        if dg is None:
+            _ready(g, b)
         return [dx], [dg, db]
 
 
@@ -576,7 +633,7 @@ class CrossBlockOp:
         Lk = kv.shape[1]
         Mq, Mk = B * Lq, B * Lk
         cdt = get_compute_dtype()
-        p = [t.detach() for t in prm]
+        p = list(prm)
         q2, kv2 = _as_f32(q).reshape(Mq, D), _as_f32(kv).reshape(Mk, D)
         qn, muq, rsq = K.layernorm_fwd(q2, D, p[0], p[1], Mq, D, cdt)
         kn, muk, rsk = K.layernorm_fwd(kv2, D, p[2], p[3], Mk, D, cdt)

@@ -117,24 +117,29 @@ def layernorm_fwd(x, ldx, gamma, beta, rows, D, out_dtype, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None, lddx=None, want_lp=False):
-    """Returns dx (fp32, row stride lddx), dx_lp (dy.dtype copy or None), dgamma, dbeta."""
+def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None, lddx=None, want_lp=False,
+                  dg_out=None, db_out=None):
+    """Returns dx (fp32, row stride lddx), dx_lp (dy.dtype copy or None), dgamma, dbeta.
+    dg_out / db_out: optional fp32 [D] gradient buffers the affine gradients are ACCUMULATED into
+    (then None is returned in their place)."""
     require_gpu(dy, x)
     dev = x.device
     if dx is None:
         dx = torch.empty((rows, D), dtype=torch.float32, device=dev)
         lddx = D
     dx_lp = torch.empty((rows, D), dtype=dy.dtype, device=dev) if want_lp else None
-    nparts = int(min(512, (rows + 3) // 4))
+    nparts = int(min(2048, (rows + 3) // 4))
     part = torch.empty((2, nparts, D), dtype=torch.float32, device=dev)
+    acc = dg_out is not None and db_out is not None
+    if acc:
+        dg, db = dg_out, db_out
+    else:
+        dgb = torch.empty((2, D), dtype=torch.float32, device=dev)
+        dg, db = dgb[0], dgb[1]
     _abi.check(_abi.lib().favit_layernorm_bwd(_p(dy), dt(dy), _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres),
                                               _p(dx), lddx, _p(dx_lp), dt(dy), _p(part[0]), _p(part[1]), nparts,
-                                              rows, D, _st()), "favit_layernorm_bwd")
-    dgb = torch.empty((2, D), dtype=torch.float32, device=dev)
-    lib = _abi.lib()
-    _abi.check(lib.favit_reduce_rows(_p(part[0]), D, _p(dgb[0]), nparts, D, 0, _st()), "favit_reduce_rows")
-    _abi.check(lib.favit_reduce_rows(_p(part[1]), D, _p(dgb[1]), nparts, D, 0, _st()), "favit_reduce_rows")
-    return dx, dx_lp, dgb[0], dgb[1]
+                                              _p(dg), _p(db), int(acc), rows, D, _st()), "favit_layernorm_bwd")
+    return (dx, dx_lp, None, None) if acc else (dx, dx_lp, dg, db)
 
 
 def reduce_rows(t2d: torch.Tensor) -> torch.Tensor:
@@ -155,16 +160,21 @@ def mhla_fold_fwd(wqkv, bqkv, wl, bl, H, dtype):
     return weff, beff
 
 
-def mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H):
+def mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H, out=None):
+    """out = (dwqkv, dbqkv, dwl, dbl) gradient buffers to ACCUMULATE into, or None for fresh tensors."""
     D = wqkv.shape[1]
     hd = D // H
     dev = wqkv.device
-    dwqkv = torch.empty_like(wqkv)
-    dbqkv = torch.empty_like(bqkv)
-    dwl = torch.empty((hd, hd), dtype=torch.float32, device=dev)
-    dbl = torch.empty(hd, dtype=torch.float32, device=dev)
+    acc = out is not None
+    if acc:
+        dwqkv, dbqkv, dwl, dbl = out
+    else:
+        dwqkv = torch.empty((3 * D, D), dtype=torch.float32, device=dev)
+        dbqkv = torch.empty(3 * D, dtype=torch.float32, device=dev)
+        dwl = torch.empty((hd, hd), dtype=torch.float32, device=dev)
+        dbl = torch.empty(hd, dtype=torch.float32, device=dev)
     _abi.check(_abi.lib().favit_mhla_fold_bwd(_p(dweff), _p(dbeff), _p(wqkv), _p(bqkv), _p(wl), _p(dwqkv), _p(dbqkv),
-                                              _p(dwl), _p(dbl), D, H, _st()), "favit_mhla_fold_bwd")
+                                              _p(dwl), _p(dbl), D, H, int(acc), _st()), "favit_mhla_fold_bwd")
     return dwqkv, dbqkv, dwl, dbl
 
 

@@ -80,6 +80,9 @@ class FusedAdamW:
             })
         self.steps = 0
         self.world = torch.distributed.get_world_size() if dist_on else 1
+        syncs = [g["sync"] for g in self.groups if g["sync"] is not None]
+        if syncs:
+            F.set_grad_ready_hook(lambda p: [s.grad_ready(p) for s in syncs])
 
     def zero_grad(self):
         for g in self.groups:

@@ -100,15 +100,16 @@ int favit_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t
  * x is the fp32 residual stream with row stride ldx (lets the head normalise x[:,0]
  * only); y has dtype y_dtype; mean/rstd [rows] are saved for backward.
  * Backward: dx = LN'(dy) (+ dres if given); optional low-precision copy dx_lp; the
- * affine gradients are produced as `nparts` partial sums [nparts, D] that
- * favit_reduce_rows folds (deterministic, no atomics).
+ * affine gradients are produced as `nparts` partial sums in a [2][nparts][D] workspace
+ * (dbeta_part = dgamma_part + nparts*D) and folded deterministically (no atomics) into dgamma[D]
+ * and dbeta[D] (accumulate=1 adds to them); dgamma = NULL skips the fold.
  * ---------------------------------------------------------------------------------- */
 int favit_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int y_dtype,
                         float* mean, float* rstd, int64_t rows, int32_t D, float eps, void* stream);
 int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x, int64_t ldx, const float* gamma,
                         const float* mean, const float* rstd, const float* dres, float* dx, int64_t lddx,
                         void* dx_lp, int lp_dtype, float* dgamma_part, float* dbeta_part, int32_t nparts,
-                        int64_t rows, int32_t D, void* stream);
+                        float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t D, void* stream);
 /* out[c] (+)= sum_r in[r*ld + c] */
 int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t accumulate,
                       void* stream);
@@ -123,9 +124,10 @@ int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_t rows, int
 int favit_mhla_fold_fwd(const float* wqkv, const float* bqkv, const float* wl, const float* bl, void* weff,
                         int weff_dtype, float* weff_f32 /* optional fp32 copy */, float* beff, int32_t D,
                         int32_t H, void* stream);
+/* accumulate=1: the four outputs are added to (gradient buffers), else overwritten */
 int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const float* wqkv, const float* bqkv,
                         const float* wl, float* dwqkv, float* dbqkv, float* dwl, float* dbl, int32_t D, int32_t H,
-                        void* stream);
+                        int32_t accumulate, void* stream);
 
 /* Windowed attention core: window index rule (mhla.py:46-83, closed form in-kernel, the
  * duplicated pad indices take part in the softmax), gather (117-126, never materialised),

@@ -230,3 +230,29 @@ def test_full_size_cfg2_batch_independence(favit, mode, tol):
         small = m(x[:2].contiguous())
     assert torch.isfinite(big).all()
     assert rel_l2(big[:2].cpu(), small.cpu()) < tol
+
+
+def test_direct_gradient_accumulation_matches_returned_grads(favit):
+    """With flat .grad buffers attached (FusedAdamW) the kernels accumulate parameter gradients in
+    place and autograd sees None; results must equal the ordinary returned-gradient path, and a
+    second backward must accumulate (torch semantics)."""
+    torch.manual_seed(0)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2,
+                                                    num_heads=4, window_size=7, use_mhla=True).to(DEV)
+    x = torch.randn(4, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (4,), device=DEV)
+    favit.train.cross_entropy(m(x), y).backward()
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for p in m.parameters():
+        p.grad = None
+    opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=1e-4), distributed=False)
+    opt.zero_grad()
+    favit.train.cross_entropy(m(x), y).backward()
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, ref[k]) < 1e-5, k
+    favit.train.cross_entropy(m(x), y).backward()
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, 2 * ref[k]) < 1e-5, k
+    w0 = m.head.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(w0, m.head.weight)
