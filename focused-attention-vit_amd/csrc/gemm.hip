@@ -885,8 +885,8 @@ __device__ __forceinline__ void wave_epilogue_half(const KParams& p, const f32x4
             *reinterpret_cast<bf16x8*>(dst) = o;
           }
         };
-        if (p.aux_out) store_vec(reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n);
-        if (p.act == FAVIT_ACT_GELU) {
+        if (p.aux_out && p.dbg != 4) store_vec(reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n);
+        if (p.act == FAVIT_ACT_GELU && p.dbg != 5) {
 #pragma unroll
           for (int c = 0; c < CPL; ++c) a[c] = epi_gelu<InT>(a[c]);
         } else if (p.act == FAVIT_ACT_DGELU) {

@@ -377,142 +377,158 @@ __global__ __launch_bounds__(256) void mhla_bwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// latent_proj fold (weight space, tiny): LDS-tiled so each launch is a few microseconds.
+// latent_proj fold (weight space, tiny): LDS-tiled, register-blocked small GEMMs so each launch is
+// a few microseconds.
 //   Weff[s,h] = Wl . Wqkv[s,h],  beff[s,h] = Wl . bqkv[s,h] + bl      (s in {k, v})
 // Column D of the [3D, D+1] augmented matrices is the bias.
 // ---------------------------------------------------------------------------------
 constexpr int FOLD_TC = 64;    // columns per workgroup
 
-// grid (ceil((D+1)/64), 2H + 1): blockIdx.y < 2H -> one (s,h) block of hd rows; == 2H -> the q rows (copy)
-template <typename T>
-__global__ __launch_bounds__(256) void fold_fwd_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqkv,
-                                                       const float* __restrict__ wl, const float* __restrict__ bl,
-                                                       T* __restrict__ weff, float* __restrict__ weff_f32,
-                                                       float* __restrict__ beff, int D, int hd, int H) {
-  extern __shared__ float sh[];            // Wl [hd][hd] + W tile [hd][64]
-  const int tc = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const int c = blockIdx.x * FOLD_TC + tc;            // column of the augmented matrix (D = bias)
-  if ((int)blockIdx.y == 2 * H) {                      // q part: plain copy / cast
-    if (c > D) return;
-    for (int r = tg; r < D; r += 4) {
-      const float v = (c < D) ? wqkv[(long)r * D + c] : bqkv[r];
-      if (c < D) {
-        weff[(long)r * D + c] = from_f32<T>(v);
-        if (weff_f32) weff_f32[(long)r * D + c] = v;
-      } else {
-        beff[r] = v;
-      }
-    }
-    return;
-  }
-  float* swl = sh;
-  float* sw = sh + hd * hd;
-  const long base = (long)D + (long)blockIdx.y * hd;   // first row of this (s,h) block
-  for (int i = threadIdx.x; i < hd * hd; i += 256) swl[i] = wl[i];
-  for (int j = tg; j < hd; j += 4) sw[j * FOLD_TC + tc] = (c < D) ? wqkv[(base + j) * D + c] : (c == D ? bqkv[base + j] : 0.f);
-  __syncthreads();
-  if (c > D) return;
-  for (int i = tg; i < hd; i += 4) {
-    float acc = 0.f;
-    for (int j = 0; j < hd; ++j) acc = fmaf(swl[i * hd + j], sw[j * FOLD_TC + tc], acc);
-    const long r = base + i;
-    if (c < D) {
-      weff[r * D + c] = from_f32<T>(acc);
-      if (weff_f32) weff_f32[r * D + c] = acc;
-    } else {
-      beff[r] = acc + bl[i];
+// C[r][c] = sum_k At[k][r] * Bt[k][c] for an [HD x 64] tile; At = [HD k][HD r], Bt = [HD k][64] in LDS.
+// Thread t owns rows r0 = TR*(t/16).. and columns c0 = 4*(t%16)..: TR x 4 register block, two vector
+// LDS reads per k for 4*TR FMAs.
+template <int HD>
+__device__ __forceinline__ void fold_tile_gemm(const float* At, const float* Bt, float (&acc)[HD / 16][4]) {
+  constexpr int TR = HD / 16;
+  const int r0 = TR * (threadIdx.x >> 4), c0 = 4 * (threadIdx.x & 15);
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < HD; ++k) {
+    float a[TR];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) a[i] = At[k * HD + r0 + i];
+    const float4 bv = *reinterpret_cast<const float4*>(Bt + k * FOLD_TC + c0);
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+      acc[i][0] = fmaf(a[i], bv.x, acc[i][0]);
+      acc[i][1] = fmaf(a[i], bv.y, acc[i][1]);
+      acc[i][2] = fmaf(a[i], bv.z, acc[i][2]);
+      acc[i][3] = fmaf(a[i], bv.w, acc[i][3]);
     }
   }
 }
 
-// dWqkv[s,h] = Wl^T . dWeff[s,h] (and the bias column); q rows are copied.  Same grid as fold_fwd.
-__global__ __launch_bounds__(256) void fold_bwd_w_kernel(const float* __restrict__ dweff, const float* __restrict__ dbeff,
-                                                         const float* __restrict__ wl, float* __restrict__ dwqkv,
-                                                         float* __restrict__ dbqkv, int D, int hd, int H,
-                                                         int accumulate) {
-  extern __shared__ float sh[];
+// grid (ceil((D+1)/64), 2H + 1): blockIdx.y < 2H -> one (s,h) block of HD rows; == 2H -> the q rows.
+// BWD = false: out = Wl . in (+ bl on the bias column), written as T (and optionally fp32)
+// BWD = true : out = Wl^T . in, fp32, optionally accumulated
+template <typename T, int HD, bool BWD>
+__global__ __launch_bounds__(256) void fold_w_kernel(const float* __restrict__ win, const float* __restrict__ bin,
+                                                     const float* __restrict__ wl, const float* __restrict__ bl,
+                                                     T* __restrict__ wout, float* __restrict__ wout_f32,
+                                                     float* __restrict__ bout, int D, int H, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float sAt[HD * HD];
+  __shared__ __attribute__((aligned(16))) float sBt[HD * FOLD_TC];
   const int tc = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const int c = blockIdx.x * FOLD_TC + tc;
-  auto put = [&](long r, float v) {
-    if (c < D) dwqkv[r * D + c] = accumulate ? dwqkv[r * D + c] + v : v;
-    else dbqkv[r] = accumulate ? dbqkv[r] + v : v;
+  auto put = [&](long r, int c, float v) {
+    if (c < D) {
+      if (BWD && accumulate) v += to_f32(wout[r * D + c]);
+      wout[r * D + c] = from_f32<T>(v);
+      if (wout_f32) wout_f32[r * D + c] = v;
+    } else if (c == D) {
+      bout[r] = (BWD && accumulate) ? bout[r] + v : v;
+    }
   };
-  if ((int)blockIdx.y == 2 * H) {
+  if ((int)blockIdx.y >= 2 * H) {                      // q part: copy / cast, HD rows per block
+    const int c = blockIdx.x * FOLD_TC + tc;
     if (c > D) return;
-    for (int r = tg; r < D; r += 4) put(r, (c < D) ? dweff[(long)r * D + c] : dbeff[r]);
+    const int rb = ((int)blockIdx.y - 2 * H) * HD;
+#pragma unroll 4
+    for (int r = rb + tg; r < rb + HD && r < D; r += 4) put(r, c, (c < D) ? win[(long)r * D + c] : bin[r]);
     return;
   }
-  float* swl = sh;
-  float* sw = sh + hd * hd;
-  const long base = (long)D + (long)blockIdx.y * hd;
-  for (int i = threadIdx.x; i < hd * hd; i += 256) swl[i] = wl[i];
-  for (int i = tg; i < hd; i += 4) sw[i * FOLD_TC + tc] = (c < D) ? dweff[(base + i) * D + c] : (c == D ? dbeff[base + i] : 0.f);
-  __syncthreads();
-  if (c > D) return;
-  for (int j = tg; j < hd; j += 4) {
-    float acc = 0.f;
-    for (int i = 0; i < hd; ++i) acc = fmaf(swl[i * hd + j], sw[i * FOLD_TC + tc], acc);
-    put(base + j, acc);
+  const long base = (long)D + (long)blockIdx.y * HD;   // first row of this (s,h) block
+  // At[k][r]: forward needs Wl[r][k] (transpose while staging), backward Wl[k][r] (as stored)
+  for (int i = threadIdx.x; i < HD * HD; i += 256) {
+    const int k = i / HD, r = i % HD;
+    sAt[i] = BWD ? wl[k * HD + r] : wl[r * HD + k];
   }
+  for (int k = tg; k < HD; k += 4) {
+    const int c = blockIdx.x * FOLD_TC + tc;
+    sBt[k * FOLD_TC + tc] = (c < D) ? win[(base + k) * D + c] : (c == D ? bin[base + k] : 0.f);
+  }
+  __syncthreads();
+  float acc[HD / 16][4];
+  fold_tile_gemm<HD>(sAt, sBt, acc);
+  constexpr int TR = HD / 16;
+  const int r0 = TR * (threadIdx.x >> 4), c0 = blockIdx.x * FOLD_TC + 4 * (threadIdx.x & 15);
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[i][j];
+      if (!BWD && c0 + j == D) v += bl[r0 + i];
+      put(base + r0 + i, c0 + j, v);
+    }
 }
 
 // dWl[i][j] += sum_c dWeff_z[i][c] Wqkv_z[j][c] + dbeff_z[i] bqkv_z[j];  dbl[i] += dbeff_z[i].
-// grid (2H): one workgroup per (s,h) block z walks the D columns in tiles of 64 and adds its
-// [hd, hd] partial with fp32 atomics (2H-way contention only).
+// grid (2H): one workgroup per (s,h) block z walks the D+1 columns in tiles of 64 (register-blocked
+// [HD x HD] accumulator) and adds its partial with fp32 atomics (2H-way contention only).
 template <int HD>
 __global__ __launch_bounds__(256) void fold_bwd_l_kernel(const float* __restrict__ dweff,
                                                          const float* __restrict__ dbeff,
                                                          const float* __restrict__ wqkv,
                                                          const float* __restrict__ bqkv, float* __restrict__ dwl,
                                                          float* __restrict__ dbl, int D) {
-  extern __shared__ float sh[];            // A tile [HD][65] (dWeff), B tile [HD][65] (Wqkv)
-  float* sa = sh;
-  float* sb = sh + HD * 65;
+  constexpr int TR = HD / 16;                          // thread block TR x TR of the [HD x HD] output
+  constexpr int LDT = HD + 1;                          // padded: transposed staging is conflict-free
+  __shared__ float sa[64 * LDT];                       // [c][i]  dWeff tile, transposed
+  __shared__ float sb[64 * LDT];                       // [c][j]  Wqkv tile, transposed
   const int tc = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const long base = (long)D + (long)blockIdx.x * HD;
-  constexpr int NJ = (HD + 63) / 64, NI = (HD + 3) / 4;
-  float acc[NI][NJ];
+  const int i0 = TR * (threadIdx.x >> 4), j0 = TR * (threadIdx.x & 15);
+  const int c = blockIdx.y * 64 + tc;                  // column D = bias column
+  float va[HD / 4], vb[HD / 4];
 #pragma unroll
-  for (int ii = 0; ii < NI; ++ii)
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) acc[ii][jj] = 0.f;
-  for (int c0 = 0; c0 <= D; c0 += 64) {            // column D = bias column
-    __syncthreads();
-    for (int r = tg; r < HD; r += 4) {
-      const int c = c0 + tc;
-      sa[r * 65 + tc] = (c < D) ? dweff[(base + r) * D + c] : (c == D ? dbeff[base + r] : 0.f);
-      sb[r * 65 + tc] = (c < D) ? wqkv[(base + r) * D + c] : (c == D ? bqkv[base + r] : 0.f);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-      const int j = tc + 64 * jj;
-      if (j < HD) {
-#pragma unroll
-        for (int ii = 0; ii < NI; ++ii) {
-          const int i = tg + 4 * ii;
-          if (i < HD) {
-            float s = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < 64; ++k) s = fmaf(sa[i * 65 + k], sb[j * 65 + k], s);
-            acc[ii][jj] += s;
-          }
-        }
-      }
-    }
+  for (int q = 0; q < HD / 4; ++q) {
+    const int r = tg + 4 * q;
+    va[q] = (c < D) ? dweff[(base + r) * D + c] : (c == D ? dbeff[base + r] : 0.f);
+    vb[q] = (c < D) ? wqkv[(base + r) * D + c] : (c == D ? bqkv[base + r] : 0.f);
   }
 #pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    const int j = tc + 64 * jj;
-    if (j < HD) {
-#pragma unroll
-      for (int ii = 0; ii < NI; ++ii) {
-        const int i = tg + 4 * ii;
-        if (i < HD) atomicAdd(dwl + (long)i * HD + j, acc[ii][jj]);
-      }
-    }
+  for (int q = 0; q < HD / 4; ++q) {
+    sa[tc * LDT + tg + 4 * q] = va[q];
+    sb[tc * LDT + tg + 4 * q] = vb[q];
   }
-  if (threadIdx.x < HD) atomicAdd(dbl + threadIdx.x, dbeff[base + threadIdx.x]);
+  __syncthreads();
+  float acc[TR][TR];
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < TR; ++j) acc[i][j] = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < 64; ++k) {
+    float a[TR], bb[TR];
+#pragma unroll
+    for (int i = 0; i < TR; ++i) { a[i] = sa[k * LDT + i0 + i]; bb[i] = sb[k * LDT + j0 + i]; }
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int j = 0; j < TR; ++j) acc[i][j] = fmaf(a[i], bb[j], acc[i][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < TR; ++j) atomicAdd(dwl + (long)(i0 + i) * HD + j0 + j, acc[i][j]);
+  if (blockIdx.y == 0 && threadIdx.x < HD) atomicAdd(dbl + threadIdx.x, dbeff[base + threadIdx.x]);
+}
+
+template <typename T, bool BWD>
+int launch_fold_w(const float* win, const float* bin, const float* wl, const float* bl, T* wout, float* wout_f32,
+                  float* bout, int D, int H, int accumulate, hipStream_t st) {
+  const int hd = D / H;
+  const dim3 grid((D + 1 + FOLD_TC - 1) / FOLD_TC, 2 * H + (D + hd - 1) / hd);
+  switch (hd) {
+    case 16: hipLaunchKernelGGL((fold_w_kernel<T, 16, BWD>), grid, dim3(256), 0, st, win, bin, wl, bl, wout, wout_f32, bout, D, H, accumulate); break;
+    case 32: hipLaunchKernelGGL((fold_w_kernel<T, 32, BWD>), grid, dim3(256), 0, st, win, bin, wl, bl, wout, wout_f32, bout, D, H, accumulate); break;
+    case 64: hipLaunchKernelGGL((fold_w_kernel<T, 64, BWD>), grid, dim3(256), 0, st, win, bin, wl, bl, wout, wout_f32, bout, D, H, accumulate); break;
+    default: return FAVIT_ERR_UNSUPPORTED;
+  }
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
 }
 
 template <typename T, int DPL, int WMAX>
@@ -586,19 +602,12 @@ extern "C" int favit_mhla_attn_bwd(const void* qkv, const void* dout, void* dqkv
 extern "C" int favit_mhla_fold_fwd(const float* wqkv, const float* bqkv, const float* wl, const float* bl, void* weff,
                                    int weff_dtype, float* weff_f32, float* beff, int32_t D, int32_t H, void* stream) {
   if (!wqkv || !bqkv || !wl || !bl || !weff || !beff || D <= 0 || H <= 0 || D % H) return FAVIT_ERR_INVALID;
-  const int hd = D / H;
-  if (hd > 128) return FAVIT_ERR_UNSUPPORTED;
-  const dim3 grid((D + 1 + FOLD_TC - 1) / FOLD_TC, 2 * H + 1);
-  const size_t lds = sizeof(float) * ((size_t)hd * hd + (size_t)hd * FOLD_TC);
   hipStream_t st = as_stream(stream);
   if (weff_dtype == FAVIT_F32)
-    hipLaunchKernelGGL((fold_fwd_kernel<float>), grid, dim3(256), lds, st, wqkv, bqkv, wl, bl, (float*)weff, weff_f32, beff, D, hd, H);
-  else if (weff_dtype == FAVIT_BF16)
-    hipLaunchKernelGGL((fold_fwd_kernel<bf16_t>), grid, dim3(256), lds, st, wqkv, bqkv, wl, bl, (bf16_t*)weff, weff_f32, beff, D, hd, H);
-  else
-    return FAVIT_ERR_INVALID;
-  FAVIT_CHECK_LAUNCH();
-  return FAVIT_OK;
+    return launch_fold_w<float, false>(wqkv, bqkv, wl, bl, (float*)weff, weff_f32, beff, D, H, 0, st);
+  if (weff_dtype == FAVIT_BF16)
+    return launch_fold_w<bf16_t, false>(wqkv, bqkv, wl, bl, (bf16_t*)weff, weff_f32, beff, D, H, 0, st);
+  return FAVIT_ERR_INVALID;
 }
 
 extern "C" int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const float* wqkv, const float* bqkv,
@@ -607,22 +616,17 @@ extern "C" int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const
   if (!dweff || !dbeff || !wqkv || !bqkv || !wl || !dwqkv || !dbqkv || !dwl || !dbl || D <= 0 || H <= 0 || D % H)
     return FAVIT_ERR_INVALID;
   const int hd = D / H;
-  if (hd > 128) return FAVIT_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
-  const dim3 grid((D + 1 + FOLD_TC - 1) / FOLD_TC, 2 * H + 1);
-  const size_t lds_w = sizeof(float) * ((size_t)hd * hd + (size_t)hd * FOLD_TC);
-  hipLaunchKernelGGL(fold_bwd_w_kernel, grid, dim3(256), lds_w, st, dweff, dbeff, wl, dwqkv, dbqkv, D, hd, H, accumulate);
-  FAVIT_CHECK_LAUNCH();
+  const int rc = launch_fold_w<float, true>(dweff, dbeff, wl, nullptr, dwqkv, nullptr, dbqkv, D, H, accumulate, st);
+  if (rc != FAVIT_OK) return rc;
   if (!accumulate) {
     (void)hipMemsetAsync(dwl, 0, sizeof(float) * hd * hd, st);
     (void)hipMemsetAsync(dbl, 0, sizeof(float) * hd, st);
   }
-  const size_t lds = sizeof(float) * (size_t)2 * hd * 65;
   switch (hd) {
-    case 16: hipLaunchKernelGGL(fold_bwd_l_kernel<16>, dim3(2 * H), dim3(256), lds, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
-    case 32: hipLaunchKernelGGL(fold_bwd_l_kernel<32>, dim3(2 * H), dim3(256), lds, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
-    case 64: hipLaunchKernelGGL(fold_bwd_l_kernel<64>, dim3(2 * H), dim3(256), lds, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
-    case 128: hipLaunchKernelGGL(fold_bwd_l_kernel<128>, dim3(2 * H), dim3(256), lds, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
+    case 16: hipLaunchKernelGGL(fold_bwd_l_kernel<16>, dim3(2 * H, (D + 64) / 64), dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
+    case 32: hipLaunchKernelGGL(fold_bwd_l_kernel<32>, dim3(2 * H, (D + 64) / 64), dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
+    case 64: hipLaunchKernelGGL(fold_bwd_l_kernel<64>, dim3(2 * H, (D + 64) / 64), dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
     default: return FAVIT_ERR_UNSUPPORTED;
   }
   FAVIT_CHECK_LAUNCH();

@@ -153,22 +153,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy,
 __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ in, long ld,
                                                             float* __restrict__ out, float* __restrict__ out1,
                                                             long rows, int cols, int accumulate) {
-  // block = 64 columns x 16 row groups; blockIdx.y = 1 selects the second stacked matrix -> out1
+  // block = 64 columns x 16 row groups; blockIdx.y = 1 selects the second stacked matrix -> out1;
+  // gridDim.z > 1 splits the rows (then the result is added atomically; accumulate mode only).
   __shared__ float red[16][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cx;
   const float* src = in + (long)blockIdx.y * rows * ld;
   float* dst = blockIdx.y ? out1 : out;
-  float s = 0.f;
-  if (col < cols)
-    for (long r = ry; r < rows; r += 16) s += src[r * ld + col];
-  red[ry][cx] = s;
+  const long per = (rows + gridDim.z - 1) / gridDim.z;
+  const long rbeg = (long)blockIdx.z * per, rend = min(rows, rbeg + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < cols) {
+    long r = rbeg + ry;
+    for (; r + 48 < rend; r += 64) {                  // 4 independent loads in flight
+      s0 += src[r * ld + col];
+      s1 += src[(r + 16) * ld + col];
+      s2 += src[(r + 32) * ld + col];
+      s3 += src[(r + 48) * ld + col];
+    }
+    for (; r < rend; r += 16) s0 += src[r * ld + col];
+  }
+  red[ry][cx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (ry == 0 && col < cols) {
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += red[q][cx];
-    dst[col] = accumulate ? dst[col] + t : t;
+    if (gridDim.z > 1) atomicAdd(dst + col, t);
+    else dst[col] = accumulate ? dst[col] + t : t;
   }
 }
 
@@ -364,8 +376,8 @@ extern "C" int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x,
 #undef LN_BWD
   FAVIT_CHECK_LAUNCH();
   if (dgamma && dbeta) {
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 63) / 64, 2), dim3(1024), 0, st, dgamma_part, (long)D, dgamma,
-                       dbeta, (long)nparts, D, accumulate);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 63) / 64, 2, accumulate ? 8 : 1), dim3(1024), 0, st, dgamma_part,
+                       (long)D, dgamma, dbeta, (long)nparts, D, accumulate);
     FAVIT_CHECK_LAUNCH();
   }
   return FAVIT_OK;
