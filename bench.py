@@ -54,7 +54,7 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(pkg, model, batch=16, steps=3):
+def cpu_baseline(pkg, model, batch=16, steps=12):
     """The CPU oracle (oracle/favit_oracle.py, a port of the reference's PyTorch-CPU path) timed on
     this box's host cores: same model config, B=16, 1 warm-up + `steps` timed fwd+bwd steps."""
     from oracle import favit_oracle as O
@@ -90,19 +90,24 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE.json configs[1]: 256)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=os.environ.get("FAVIT_DIST_BACKEND", "nccl"),
+                    help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
     ap.add_argument("--no-gemm-trace", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", local % ndev)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     pkg = importlib.import_module("focused-attention-vit_amd")
     pkg._abi.lib()                                   # no HIP library -> fail loudly
