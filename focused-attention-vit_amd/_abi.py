@@ -61,7 +61,7 @@ _SIGS = {
     "favit_sppp_centroids": ([vp, vp, i32, i32, i32, vp], C.c_int),
     "favit_sppp_posenc_fwd": ([vp, vp, vp, i32, i32, i32, i32, vp], C.c_int),
     "favit_cross_entropy": ([vp, vp, vp, vp, i32, i32, f32, vp], C.c_int),
-    "favit_adamw": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp], C.c_int),
+    "favit_adamw": ([vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp], C.c_int),
 }
 
 _lib = None

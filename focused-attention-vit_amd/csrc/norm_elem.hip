@@ -298,8 +298,8 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
 
 // torch.optim.AdamW semantics (decoupled weight decay), one flat fp32 chunk
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2, float gscale) {
+                             float* __restrict__ v, bf16_t* __restrict__ p_lp, long n, float lr, float b1, float b2,
+                             float eps, float wd, float bc1, float bc2, float gscale) {
   const float step = lr / bc1, rbc2 = rsqrtf(bc2);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
@@ -308,6 +308,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
     pi -= step * mi / (sqrtf(vi) * rbc2 + eps);
     p[i] = pi; m[i] = mi; v[i] = vi;
+    if (p_lp) p_lp[i] = (bf16_t)pi;
   }
 }
 
@@ -485,12 +486,12 @@ extern "C" int favit_cross_entropy(const float* logits, const int64_t* labels, f
   return FAVIT_OK;
 }
 
-extern "C" int favit_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                           float beta2, float eps, float weight_decay, float bias_c1, float bias_c2, float grad_scale,
-                           void* stream) {
+extern "C" int favit_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                           float beta1, float beta2, float eps, float weight_decay, float bias_c1, float bias_c2,
+                           float grad_scale, void* stream) {
   if (!p || !g || !m || !v || n < 0) return FAVIT_ERR_INVALID;
   if (n == 0) return FAVIT_OK;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, grad_scale);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), p, g, m, v, (bf16_t*)p_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, grad_scale);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }

@@ -13,6 +13,7 @@ compute-dtype copy that feeds the backward GEMMs.
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -76,6 +77,20 @@ def bump_weight_epoch() -> None:
 
 
 _WCACHE = {}
+# parameter storage -> (fp32 flat buffer, bf16 mirror) kept fresh by the fused optimizer (train.FusedAdamW)
+_LP_MIRRORS = []
+
+
+def register_lp_mirror(flat_p: torch.Tensor, flat_lp: torch.Tensor) -> None:
+    """flat_lp is a bf16 mirror of the fp32 parameter buffer flat_p.  The owner (train.FusedAdamW)
+    keeps it fresh: the AdamW kernel rewrites it with every update and zero_grad() re-casts it, so
+    parameters edited in place between steps (``.data.copy_``, ``nn.init.*``) are picked up at the
+    next zero_grad()."""
+    _LP_MIRRORS.append((weakref.ref(flat_p), flat_lp))
+
+
+def clear_lp_mirrors() -> None:
+    _LP_MIRRORS.clear()
 
 
 def wcast(w: torch.Tensor) -> torch.Tensor:
@@ -84,6 +99,17 @@ def wcast(w: torch.Tensor) -> torch.Tensor:
     w = w.detach()
     if w.dtype == cdt and w.is_contiguous():
         return w
+    if cdt == torch.bfloat16 and w.dtype == torch.float32 and w.is_contiguous():
+        ptr = w.data_ptr()
+        for ref, lp in list(_LP_MIRRORS):
+            fp = ref()
+            if fp is None:                    # the optimizer that owned this mirror is gone
+                _LP_MIRRORS.remove((ref, lp))
+                continue
+            base = fp.data_ptr()
+            if base <= ptr < base + 4 * fp.numel():
+                off = (ptr - base) // 4
+                return lp[off:off + w.numel()].view(w.shape)
     key = (w.data_ptr(), tuple(w.shape))
     tag = (w._version, _STATE["epoch"], cdt)
     hit = _WCACHE.get(key)

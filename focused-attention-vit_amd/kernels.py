@@ -314,8 +314,8 @@ def cross_entropy(logits, labels, grad_scale=None):
     return loss_rows, dlog
 
 
-def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, p_lp=None):
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
-    _abi.check(_abi.lib().favit_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, bc1, bc2,
-                                      grad_scale, _st()), "favit_adamw")
+    _abi.check(_abi.lib().favit_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_lp), p.numel(), lr, beta1, beta2, eps, wd, bc1,
+                                      bc2, grad_scale, _st()), "favit_adamw")

@@ -76,8 +76,12 @@ class FusedAdamW:
                 "flat": flat, "lr": g.get("lr", lr), "betas": g.get("betas", betas), "eps": g.get("eps", eps),
                 "weight_decay": g.get("weight_decay", weight_decay),
                 "m": torch.zeros_like(flat.flat_p), "v": torch.zeros_like(flat.flat_p),
+                "lp": torch.empty(flat.numel, dtype=torch.bfloat16, device=flat.flat_p.device) if flat.flat_p.is_cuda else None,
                 "sync": GradSync(flat, bucket_mb) if dist_on else None,
             })
+            if self.groups[-1]["lp"] is not None:
+                K.cast(flat.flat_p, torch.bfloat16, out=self.groups[-1]["lp"])
+                F.register_lp_mirror(flat.flat_p, self.groups[-1]["lp"])
         self.steps = 0
         self.world = torch.distributed.get_world_size() if dist_on else 1
         syncs = [g["sync"] for g in self.groups if g["sync"] is not None]
@@ -87,6 +91,8 @@ class FusedAdamW:
     def zero_grad(self):
         for g in self.groups:
             g["flat"].zero_grad()
+            if g["lp"] is not None:          # pick up in-place parameter edits made between steps
+                K.cast(g["flat"].flat_p, torch.bfloat16, out=g["lp"])
 
     def step(self):
         self.steps += 1
@@ -95,7 +101,7 @@ class FusedAdamW:
                 g["sync"].finish(average=False)
             f = g["flat"]
             K.adamw(f.flat_p, f.flat_g, g["m"], g["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                    g["weight_decay"], self.steps, grad_scale=1.0 / self.world)
+                    g["weight_decay"], self.steps, grad_scale=1.0 / self.world, p_lp=g["lp"])
         F.bump_weight_epoch()
 
 

@@ -204,8 +204,10 @@ int favit_sppp_posenc_fwd(const float* x, const float* cent, float* y, int32_t B
  * ---------------------------------------------------------------------------------- */
 int favit_cross_entropy(const float* logits, const int64_t* labels, float* loss_rows, float* dlogits, int32_t B,
                         int32_t C, float grad_scale, void* stream);
-int favit_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                float eps, float weight_decay, float bias_c1, float bias_c2, float grad_scale, void* stream);
+/* p_bf16 (optional, [n] bf16): refreshed compute-dtype copy of the updated parameters */
+int favit_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                float beta2, float eps, float weight_decay, float bias_c1, float bias_c2, float grad_scale,
+                void* stream);
 
 #ifdef __cplusplus
 }

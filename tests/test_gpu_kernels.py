@@ -281,11 +281,13 @@ def test_cross_entropy_and_adamw(K):
     pr = p.clone().requires_grad_(True)
     opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=0.05)
     m, v = torch.zeros_like(p), torch.zeros_like(p)
+    lp = torch.empty_like(p, dtype=torch.bfloat16)
     for step in (1, 2, 3):
         pr.grad = gr.clone()
         opt.step()
-        K.adamw(p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.05, step)
+        K.adamw(p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.05, step, p_lp=lp)
     assert rel_l2(p, pr.detach()) < 1e-6
+    assert torch.equal(lp, p.to(torch.bfloat16))
 
 
 def test_sppp_kernels_vs_golden(K):
