@@ -11,7 +11,7 @@ The math runs in hand-written HIP kernels (``csrc/``) reached through the C ABI 
 ``include/favit.h``; there is no CPU or PyTorch-op fallback.
 """
 from . import _abi
-from .functional import get_compute_dtype, set_compute_dtype
+from .functional import get_compute_dtype, set_compute_dtype, set_side_stream, set_direct_grads
 from . import kernels, functional, models
 from . import dp, train
 

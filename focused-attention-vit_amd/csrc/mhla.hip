@@ -82,6 +82,57 @@ __device__ __forceinline__ void vstore(T* p, const float (&v)[N]) {
 
 __device__ __forceinline__ float sum8(float v) { return dpp_sum8(v); }
 
+// A lane's DPL-element slice kept in its storage form for dot products: bf16 pairs stay packed and
+// are consumed by v_dot2c_f32_bf16 (2 MACs per instruction, no unpack); fp32 stays fp32.
+template <typename T, int N> struct Slice;
+template <int N> struct Slice<float, N> {
+  float v[N];
+  __device__ __forceinline__ void load(const float* p) { vload<float, N>(p, v); }
+  __device__ __forceinline__ float dot(const Slice& o) const {
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < N; ++d) acc = fmaf(v[d], o.v[d], acc);
+    return acc;
+  }
+  __device__ __forceinline__ void unpack(float (&o)[N]) const {
+#pragma unroll
+    for (int d = 0; d < N; ++d) o[d] = v[d];
+  }
+};
+template <int N> struct Slice<bf16_t, N> {
+  uint32_t w[N / 2];
+  __device__ __forceinline__ void load(const bf16_t* p) {
+    constexpr int BYTES = N * 2;
+    if constexpr (BYTES % 16 == 0) {
+#pragma unroll
+      for (int c = 0; c < BYTES / 16; ++c) {
+        const uint4 u = reinterpret_cast<const uint4*>(p)[c];
+        w[4 * c] = u.x; w[4 * c + 1] = u.y; w[4 * c + 2] = u.z; w[4 * c + 3] = u.w;
+      }
+    } else if constexpr (BYTES == 8) {
+      const uint2 u = *reinterpret_cast<const uint2*>(p);
+      w[0] = u.x; w[1] = u.y;
+    } else {
+      w[0] = *reinterpret_cast<const uint32_t*>(p);
+    }
+  }
+  __device__ __forceinline__ float dot(const Slice& o) const {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j)
+      acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, w[j]), __builtin_bit_cast(bf2, o.w[j]), acc, false);
+    return acc;
+  }
+  __device__ __forceinline__ void unpack(float (&o)[N]) const {
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+      o[2 * j] = __uint_as_float(w[j] << 16);
+      o[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+    }
+  }
+};
+
 // LDS image of rows of one [*, hd] tensor: a contiguous "main" run of rows plus the head
 // rows [0, head_n) and the tail rows [tail_lo, L) that the wrap rule can reach.
 struct RowImage {
@@ -131,6 +182,7 @@ struct AttnArgs {
   void* out;      // fwd: o ; bwd: dqkv
   const uint8_t* mask;
   int B, L, H, hd, W;
+  int rb;              // backward: key/query rows per workgroup (32 - 2h keeps phase 1 to one pass)
   float inv_sqrt_hd;   // unused (true division is applied), kept for clarity
   uint32_t thresh;
   float keep_scale;
@@ -139,7 +191,7 @@ struct AttnArgs {
 
 // scores + softmax of one query row (8 lanes own the row; every lane ends with all p[w])
 template <typename T, int DPL, int WMAX>
-__device__ __forceinline__ void row_softmax(const float (&q)[DPL], const char* ldsK, const RowImage& imK, int rs,
+__device__ __forceinline__ void row_softmax(const Slice<T, DPL>& q, const char* ldsK, const RowImage& imK, int rs,
                                             int lane8, int i, int b, int head, const AttnArgs& a, int (&idx)[WMAX],
                                             float (&p)[WMAX]) {
   const int h = a.W >> 1;
@@ -151,12 +203,9 @@ __device__ __forceinline__ void row_softmax(const float (&q)[DPL], const char* l
     idx[w] = 0;
     if (w < a.W) {
       idx[w] = win_idx(i, w, a.L, a.W, h);
-      float kf[DPL];
-      vload<T, DPL>(reinterpret_cast<const T*>(ldsK + imK.slot(idx[w]) * rs) + lane8 * DPL, kf);
-      float acc = 0.f;
-#pragma unroll
-      for (int d = 0; d < DPL; ++d) acc = fmaf(q[d], kf[d], acc);
-      s = sum8(acc) / sq;                                         // mhla.py:133 (true division)
+      Slice<T, DPL> kf;
+      kf.load(reinterpret_cast<const T*>(ldsK + imK.slot(idx[w]) * rs) + lane8 * DPL);
+      s = sum8(q.dot(kf)) / sq;                                   // mhla.py:133 (true division)
       if (a.mask && a.mask[((long)b * a.L + i) * a.L + idx[w]] == 0) s = -INFINITY;   // mhla.py:143
     }
     p[w] = s;
@@ -200,8 +249,8 @@ __global__ __launch_bounds__(256) void mhla_fwd_kernel(AttnArgs a) {
     const int iq = base + qs;
     const bool valid = iq < r1;
     const int i = valid ? iq : r1 - 1;
-    float q[DPL];
-    vload<T, DPL>(qkv + (tok0 + i) * ld + head * HD + lane8 * DPL, q);
+    Slice<T, DPL> q;
+    q.load(qkv + (tok0 + i) * ld + head * HD + lane8 * DPL);
     int idx[WMAX];
     float p[WMAX];
     row_softmax<T, DPL, WMAX>(q, ldsK, im, rs, lane8, i, b, head, a, idx, p);
@@ -232,7 +281,7 @@ __global__ __launch_bounds__(256) void mhla_bwd_kernel(AttnArgs a) {
   constexpr int HD = 8 * DPL;
   const int tid = threadIdx.x, lane8 = tid & 7, qs = tid >> 3;
   const int head = blockIdx.y, b = blockIdx.z;
-  const int r0 = blockIdx.x * BWD_RB, r1 = min(a.L, r0 + BWD_RB);
+  const int r0 = blockIdx.x * a.rb, r1 = min(a.L, r0 + a.rb);
   const int L = a.L, W = a.W, h = W >> 1, D = a.H * HD;
   const long ld = 3L * D, tok0 = (long)b * L;
   const T* qkv = reinterpret_cast<const T*>(a.qkv);
@@ -282,9 +331,9 @@ __global__ __launch_bounds__(256) void mhla_bwd_kernel(AttnArgs a) {
     const bool valid = s < n_q;
     const int sc = valid ? s : n_q - 1;
     const int i = qrow_of(sc);
-    float q[DPL], g[DPL];
-    vload<T, DPL>(reinterpret_cast<const T*>(ldsQ + sc * rs) + lane8 * DPL, q);
-    vload<T, DPL>(reinterpret_cast<const T*>(ldsG + sc * rs) + lane8 * DPL, g);
+    Slice<T, DPL> q, g;
+    q.load(reinterpret_cast<const T*>(ldsQ + sc * rs) + lane8 * DPL);
+    g.load(reinterpret_cast<const T*>(ldsG + sc * rs) + lane8 * DPL);
     int idx[WMAX];
     float p[WMAX];
     row_softmax<T, DPL, WMAX>(q, ldsK, imK, rs, lane8, i, b, head, a, idx, p);
@@ -295,12 +344,9 @@ __global__ __launch_bounds__(256) void mhla_bwd_kernel(AttnArgs a) {
       dp[w] = 0.f;
       pd[w] = 0.f;
       if (w < W) {
-        float vf[DPL];
-        vload<T, DPL>(reinterpret_cast<const T*>(ldsV + imK.slot(idx[w]) * rs) + lane8 * DPL, vf);
-        float acc = 0.f;
-#pragma unroll
-        for (int d = 0; d < DPL; ++d) acc = fmaf(g[d], vf[d], acc);
-        float t = sum8(acc);                       // d(P_dropped)[w]
+        Slice<T, DPL> vf;
+        vf.load(reinterpret_cast<const T*>(ldsV + imK.slot(idx[w]) * rs) + lane8 * DPL);
+        float t = sum8(g.dot(vf));                 // d(P_dropped)[w]
         float keep = 1.f;
         if (a.thresh) {
           const uint64_t e = (((uint64_t)b * a.H + head) * L + i) * W + w;
@@ -544,12 +590,12 @@ int launch_attn(bool bwd, const AttnArgs& a, hipStream_t st) {
     dim3 grid((a.L + FWD_QPB - 1) / FWD_QPB, a.H, a.B);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
   } else {
-    const int krows = (BWD_RB + 4 * h) + 2 * (2 * h + 1);
+    const int krows = (a.rb + 4 * h) + 2 * (2 * h + 1);
     const size_t lds = (size_t)2 * krows * rs + (size_t)2 * 64 * rs + (size_t)2 * 64 * WMAX * 4;
     if (lds > 160 * 1024) return FAVIT_ERR_UNSUPPORTED;
     auto k = mhla_bwd_kernel<T, DPL, WMAX>;
     if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((a.L + BWD_RB - 1) / BWD_RB, a.H, a.B);
+    dim3 grid((a.L + a.rb - 1) / a.rb, a.H, a.B);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
   }
   FAVIT_CHECK_LAUNCH();
@@ -576,6 +622,7 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
   AttnArgs a;
   a.qkv = qkv; a.dout = dout; a.out = out; a.mask = mask;
   a.B = B; a.L = L; a.H = H; a.hd = hd; a.W = W;
+  a.rb = BWD_RB - 2 * (W / 2);
   a.inv_sqrt_hd = 0.f;
   a.thresh = dropout_threshold(p);
   a.keep_scale = 1.0f / (1.0f - p);
