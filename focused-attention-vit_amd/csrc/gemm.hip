@@ -56,6 +56,7 @@ struct KParams {
   uint64_t drop_seed;
   int ntiles;          // output tiles per (split, batch)
   int xcd_split;       // 1: 1-D grid of ntiles*nsplit blocks, all tiles of a split on one XCD
+  int store_policy;    // cache policy of the epilogue's output stores (store16_policy)
   int stagger_ticks;   // 100 MHz ticks the second resident set of p4 workgroups waits at start
   int dbg;     // experiments only (FAVIT_GEMM_DBG): 1 = skip epilogue, 2 = skip main loop
 };
@@ -820,6 +821,25 @@ __device__ __forceinline__ void direct_epilogue(const KParams& p, const f32x4 (&
 // accumulator block goes through LDS in two 32-row halves so that every global access is a full
 // row segment (64 cols = 128 B bf16 / 256 B f32 contiguous per row, 16 B per lane) instead of the
 // 32-B pieces of the raw MFMA layout (which measured 1.7 TB/s on the two-output fc1 epilogue).
+// 16-byte output store with a cache policy: 0 plain, 1 non-temporal (nt), 2 write-through (sc1).
+// GEMM outputs are written once and not re-read by this kernel; keeping them out of the XCD L2
+// protects the A/B operand lines that co-resident workgroups still share.
+__device__ __forceinline__ void store16_policy(void* ptr, uint4 v, int policy) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 t = {v.x, v.y, v.z, v.w};
+  if (policy == 1) {
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(ptr));
+  } else if (policy == 2) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(t) : "memory");
+  } else if (policy == 3) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(ptr), "v"(t) : "memory");
+  } else if (policy == 4) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(ptr), "v"(t) : "memory");
+  } else {
+    *reinterpret_cast<u32x4*>(ptr) = t;
+  }
+}
+
 constexpr int WEPI_LD = 68;                         // padded fp32 row
 constexpr int WEPI_BYTES = 32 * WEPI_LD * 4;        // 8704 B per wave
 
@@ -876,14 +896,16 @@ __device__ __forceinline__ void wave_epilogue_half(const KParams& p, const f32x4
           a[4 * c4 + 2] = fmaf(a[4 * c4 + 2], p.alpha, b.z); a[4 * c4 + 3] = fmaf(a[4 * c4 + 3], p.alpha, b.w);
         }
         auto store_vec = [&](OutT* dst) {
+          uint4 raw;
           if constexpr (sizeof(OutT) == 4) {
-            *reinterpret_cast<float4*>(dst) = make_float4(a[0], a[1], a[2], a[3]);
+            raw = make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
           } else {
             bf16x8 o;
 #pragma unroll
             for (int c = 0; c < 8; ++c) o[c] = (bf16_t)a[c];
-            *reinterpret_cast<bf16x8*>(dst) = o;
+            raw = __builtin_bit_cast(uint4, o);
           }
+          store16_policy(dst, raw, p.store_policy);
         };
         if (p.aux_out && p.dbg != 4) store_vec(reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n);
         if (p.act == FAVIT_ACT_GELU && p.dbg != 5) {
@@ -895,8 +917,8 @@ __device__ __forceinline__ void wave_epilogue_half(const KParams& p, const f32x4
           if constexpr (sizeof(InT) == 4) {
 #pragma unroll
             for (int c4 = 0; c4 < CPL / 4; ++c4) {
-              const float4 t = *reinterpret_cast<const float4*>(ai + 4 * c4);
-              x[4 * c4] = t.x; x[4 * c4 + 1] = t.y; x[4 * c4 + 2] = t.z; x[4 * c4 + 3] = t.w;
+              const f32x4 t = *reinterpret_cast<const f32x4*>(ai + 4 * c4);
+              x[4 * c4] = t[0]; x[4 * c4 + 1] = t[1]; x[4 * c4 + 2] = t[2]; x[4 * c4 + 3] = t[3];
             }
           } else {
 #pragma unroll
@@ -916,8 +938,8 @@ __device__ __forceinline__ void wave_epilogue_half(const KParams& p, const f32x4
         if (p.residual) {
 #pragma unroll
           for (int c4 = 0; c4 < CPL / 4; ++c4) {
-            const float4 r = *reinterpret_cast<const float4*>(p.residual + m * p.ld_res + n + 4 * c4);
-            a[4 * c4] += r.x; a[4 * c4 + 1] += r.y; a[4 * c4 + 2] += r.z; a[4 * c4 + 3] += r.w;
+            const f32x4 r = *reinterpret_cast<const f32x4*>(p.residual + m * p.ld_res + n + 4 * c4);
+            a[4 * c4] += r[0]; a[4 * c4 + 1] += r[1]; a[4 * c4 + 2] += r[2]; a[4 * c4 + 3] += r[3];
           }
         }
         store_vec(C + m * p.ldc + n);
@@ -1350,6 +1372,9 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.alpha = g->alpha;
   { const char* e = getenv("FAVIT_GEMM_DBG"); kp.dbg = e ? atoi(e) : 0; }
   { const char* e = getenv("FAVIT_GEMM_STAGGER"); kp.stagger_ticks = e ? atoi(e) : 0; }
+  // epilogue outputs / residual / aux reads are touched once: non-temporal keeps them from evicting
+  // the operand panels the co-resident workgroups share in L2 (fc2: 140 -> 114 us)
+  { const char* e = getenv("FAVIT_GEMM_STORE"); kp.store_policy = e ? atoi(e) : 1; }
   if (g->dropout_p < 0.f || g->dropout_p >= 1.f) return FAVIT_ERR_INVALID;
   kp.drop_thresh = dropout_threshold(g->dropout_p);
   kp.drop_scale = 1.0f / (1.0f - g->dropout_p);
