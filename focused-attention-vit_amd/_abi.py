@@ -39,6 +39,7 @@ _SIGS = {
     "favit_abi_version": ([], C.c_int),
     "favit_strerror": ([C.c_int], C.c_char_p),
     "favit_gemm": ([C.POINTER(GemmDesc), vp], C.c_int),
+    "favit_gemm_grouped_tn": ([C.POINTER(GemmDesc), i32, vp], C.c_int),
     "favit_cast": ([vp, C.c_int, vp, C.c_int, i64, vp], C.c_int),
     "favit_layernorm_fwd": ([vp, i64, vp, vp, vp, C.c_int, vp, vp, i64, i32, f32, vp], C.c_int),
     "favit_layernorm_bwd": ([vp, C.c_int, vp, i64, vp, vp, vp, vp, vp, i64, vp, C.c_int, vp, vp, i32, vp, vp, i32,

@@ -971,17 +971,14 @@ __device__ __forceinline__ void wave_epilogue(const KParams& p, const f32x4 (&ac
 }
 
 template <bool AK, bool BKM, typename OutT>
-__global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_kernel(KParams p) {
+__device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, int z) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
 
-  int tile, split;
-  tile_and_split(p, tile, split);
   const long m0 = (long)(tile / p.tiles_n) * P4_BM;
   const long n0 = (long)(tile % p.tiles_n) * BN;
-  const int z = blockIdx.z;
   const long zo = z / p.batch_inner, zi = z % p.batch_inner;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
   const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
@@ -1091,6 +1088,34 @@ __global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_kernel(KParams p) 
   __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
   wave_epilogue<bf16_t, OutT>(p, acc, C, m0 + wr * 64, n0 + wc * 64, lane,
                               reinterpret_cast<float*>(smem + wave * WEPI_BYTES), split == 0);
+}
+
+template <bool AK, bool BKM, typename OutT>
+__global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_kernel(KParams p) {
+  int tile, split;
+  tile_and_split(p, tile, split);
+  p4_body<AK, BKM, OutT>(p, tile, split, blockIdx.z);
+}
+
+// Grouped weight-gradient launch: several dW = dY^T.X problems that share the token dimension (the
+// four Linear layers of one transformer block) run as ONE grid.  Their tiles together fill the 64
+// workgroup slots of an XCD with a single K-split per XCD (8 splits in all instead of 24 each), which
+// cuts the fp32-atomic traffic of the split-K reduction ~3x and keeps every split's token rows in
+// one XCD's L2.
+constexpr int GROUP_MAX = 8;
+struct GroupParams {
+  int count, total_tiles, nsplit, pad_;
+  int tile_off[GROUP_MAX + 1];
+  KParams p[GROUP_MAX];
+};
+
+__global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_grouped_tn_kernel(GroupParams gp) {
+  const int h = blockIdx.x, xcd = h & 7, idx = h >> 3;
+  const int split = xcd + 8 * (idx / gp.total_tiles);
+  const int t = idx % gp.total_tiles;
+  int i = 0;
+  while (i + 1 < gp.count && t >= gp.tile_off[i + 1]) ++i;
+  p4_body<false, false, float>(gp.p[i], t - gp.tile_off[i], split, 0);
 }
 
 template <typename Kn>
@@ -1496,4 +1521,81 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
       default: return launch(gemm_f32_kernel<false, false>, kp, grid, st);
     }
   }
+}
+
+extern "C" int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void* stream) {
+  if (!gs || count <= 0 || count > GROUP_MAX) return FAVIT_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  GroupParams gp;
+  gp.count = count;
+  gp.pad_ = 0;
+  const long K = gs[0].K;
+  if (K <= 0 || (K % P4_BK) != 0) return FAVIT_ERR_UNSUPPORTED;
+  int off = 0;
+  for (int i = 0; i < count; ++i) {
+    const favit_gemm_t* g = gs + i;
+    if (!g->A || !g->B || !g->C || g->M <= 0 || g->N <= 0) return FAVIT_ERR_INVALID;
+    if (g->K != K || g->in_dtype != FAVIT_BF16 || g->out_dtype != FAVIT_F32 || g->a_kmajor || g->b_kmajor ||
+        (g->batch > 1) || g->act != FAVIT_ACT_NONE || g->aux_in || g->aux_out || g->residual || g->bias ||
+        g->dropout_p > 0.f || g->alpha != 1.0f)
+      return FAVIT_ERR_UNSUPPORTED;
+    if (!aligned(g->A, 16) || !aligned(g->B, 16) || (g->lda % 8) || (g->ldb % 8) || (g->M % 8) || (g->N % 8) ||
+        g->M < 8 || g->N < 8)
+      return FAVIT_ERR_UNSUPPORTED;
+    KParams& kp = gp.p[i];
+    kp.A = g->A; kp.B = g->B; kp.C = g->C;
+    kp.bias = nullptr; kp.aux_in = nullptr; kp.aux_out = nullptr; kp.residual = nullptr;
+    kp.a_rowsum = g->a_rowsum;
+    kp.M = g->M; kp.N = g->N; kp.K = K;
+    kp.lda = g->lda; kp.ldb = g->ldb; kp.ldc = g->ldc;
+    kp.ld_aux_in = kp.ld_aux_out = kp.ld_res = 0;
+    kp.sAo = kp.sAi = kp.sBo = kp.sBi = kp.sCo = kp.sCi = 0;
+    kp.batch_inner = 1;
+    kp.act = FAVIT_ACT_NONE;
+    kp.atomic = 1;
+    kp.a_vec = kp.b_vec = 1;
+    kp.c_vec = 0;
+    kp.tiles_n = (int)((g->N + BN - 1) / BN);
+    kp.ntiles = (int)(((g->M + P4_BM - 1) / P4_BM) * kp.tiles_n);
+    kp.xcd_split = 1;
+    kp.alpha = 1.0f;
+    kp.drop_thresh = 0; kp.drop_scale = 1.0f; kp.drop_seed = 0;
+    kp.store_policy = 0; kp.stagger_ticks = 0; kp.dbg = 0;
+    gp.tile_off[i] = off;
+    off += kp.ntiles;
+  }
+  gp.tile_off[count] = off;
+  gp.total_tiles = off;
+  // splits = 8*s: one group of s splits per XCD; pick s that fills the 64 slots of an XCD best
+  double best = -1.0;
+  long best_s = 1;
+  for (long s = 1; s <= 4; ++s) {
+    const long w = (long)off * s;
+    const double util = (double)w / (double)(((w + 63) / 64) * 64);
+    if (util > best + 0.02) { best = util; best_s = s; }
+  }
+  long nsplit = 8 * best_s;
+  long kps = (K + nsplit - 1) / nsplit;
+  kps = ((kps + P4_BK - 1) / P4_BK) * P4_BK;
+  if ((nsplit - 1) * kps >= K) return FAVIT_ERR_UNSUPPORTED;       // too few tokens to split 8 ways
+  gp.nsplit = (int)nsplit;
+  for (int i = 0; i < count; ++i) {
+    gp.p[i].k_per_split = kps;
+    if (!gs[i].accumulate) {
+      const long total = gs[i].M * gs[i].N;
+      const int zb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+      hipLaunchKernelGGL(zero_c_kernel, dim3(zb, 1, 1), dim3(256), 0, st, reinterpret_cast<float*>(gs[i].C), gs[i].M,
+                         gs[i].N, gs[i].ldc, 0L, 0L, 1);
+      FAVIT_CHECK_LAUNCH();
+    }
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p4_grouped_tn_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_p4_grouped_tn_kernel, dim3((unsigned)(off * nsplit)), dim3(P4_THREADS), P4_LDS, st, gp);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
 }

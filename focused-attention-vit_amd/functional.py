@@ -220,6 +220,35 @@ def lin_bwd_x(dy, w_c, M, N, Kd, out_dtype, *, dgelu_pre=None, drop=(0.0, 0)):
     return dx
 
 
+# Weight-gradient GEMMs of one block are collected and issued as ONE grouped launch
+# (favit_gemm_grouped_tn): see EncoderOp.bwd / flush_wgrads.
+_WG = {"list": None}
+
+
+def begin_wgrads() -> None:
+    _WG["list"] = []
+
+
+def flush_wgrads() -> None:
+    """Launch the collected weight-gradient GEMMs (grouped if the library can, else one by one)."""
+    lst = _WG["list"]
+    if not lst:
+        return
+    _WG["list"] = [] if lst is not None else None
+    probs = [(dy, a, dw, db, acc) for dy, a, dw, db, acc, _ in lst]
+    if len(probs) < 2 or not K.gemm_grouped_tn(probs):
+        for dy, a, dw, db, acc in probs:
+            K.gemm(dy, a, dw, dy.shape[1], a.shape[1], dy.shape[0], dy.stride(0), a.stride(0), dw.stride(0),
+                   a_kmajor=False, b_kmajor=False, a_rowsum=db, accumulate=acc)
+    for *_, ready in lst:
+        _ready(*ready)
+
+
+def end_wgrads() -> None:
+    flush_wgrads()
+    _WG["list"] = None
+
+
 def lin_bwd_w(dy, a, M, N, Kd, want_bias=True, wp=None, bp=None):
     """dw[N,K] = dy[M,N]^T @ a[M,K] (fp32, split-K over the tokens), db[N] = column sums of dy (fused).
     If the parameters wp / bp own usable .grad buffers the results are accumulated there and None
@@ -230,6 +259,11 @@ def lin_bwd_w(dy, a, M, N, Kd, want_bias=True, wp=None, bp=None):
     db = None
     if want_bias:
         db = tb if tb is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
+    if _WG["list"] is not None and dy.dtype == torch.bfloat16:
+        # deferred: joins the block's grouped weight-gradient launch
+        _WG["list"].append((dy, a, dw, db, tw is not None,
+                            [p for p, t in ((wp, tw), (bp, tb)) if t is not None]))
+        return (None if tw is not None else dw), (None if tb is not None else db)
     with _side_stream(dy, a, dw, db):
         K.gemm(dy, a, dw, N, Kd, M, N, Kd, Kd, a_kmajor=False, b_kmajor=False, a_rowsum=db,
                accumulate=tw is not None)
@@ -323,6 +357,7 @@ class MHLAChain:
         dqkv = K.mhla_attn_bwd(qkv, do, B, L, H, hd, self.W, mask, pa, sa)
         dxn = lin_bwd_x(dqkv, weff, M, 3 * D, D, xn.dtype)
         dweff, dbeff = lin_bwd_w(dqkv, xn, M, 3 * D, D)
+        flush_wgrads()                      # dW2, dW1, dWproj, dWeff of this block: one grouped launch
         tg = [_gt(p) for p in (wqkv, bqkv, wl, bl)]
         if all(t is not None for t in tg):
             with _side_stream(dweff, dbeff):
@@ -617,6 +652,7 @@ class EncoderOp:
         g = dy.reshape(M, D)
         g_lp = _as_cdt(g)
         grads = []
+        begin_wgrads()
         for bs, tp in zip(reversed(self.blocks), reversed(tapes)):
             x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm = tp
             dxn2, gm = bs.mlp.bwd(sm, g_lp)
@@ -629,8 +665,10 @@ class EncoderOp:
                                                 dg_out=_gt(g1), db_out=_gt(b1))
             if dg1 is None:
                 _ready(g1, b1)
+            flush_wgrads()
             join_side_stream()
             grads = [dg1, db1] + ga + [dg2, db2] + gm + grads
+        end_wgrads()
         return [g.reshape(B, L, D)], grads
 
 

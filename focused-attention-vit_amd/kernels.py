@@ -97,6 +97,43 @@ def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias
     GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, key, (M, N, K, batch)))
 
 
+def gemm_grouped_tn(problems) -> bool:
+    """One launch for several weight-gradient GEMMs dW = dY^T X that share the token dim.
+    problems: list of (dy [T,N], a [T,K], dw [N,K] fp32, db [N] fp32 or None, accumulate: bool).
+    Returns False if the library cannot group them (caller falls back to single launches)."""
+    n = len(problems)
+    if n == 0:
+        return True
+    arr = (GemmDesc * n)()
+    T = problems[0][0].shape[0]
+    for d, (dy, a, dw, db, acc) in zip(arr, problems):
+        require_gpu(dy, a, dw)
+        if dy.dtype != torch.bfloat16 or a.dtype != torch.bfloat16 or dw.dtype != torch.float32 or dy.shape[0] != T:
+            return False
+        N, Kd = dy.shape[1], a.shape[1]
+        d.A, d.B, d.C = dy.data_ptr(), a.data_ptr(), dw.data_ptr()
+        d.a_rowsum = db.data_ptr() if db is not None else None
+        d.M, d.N, d.K = N, Kd, T
+        d.lda, d.ldb, d.ldc = dy.stride(0), a.stride(0), dw.stride(0)
+        d.batch, d.batch_inner = 1, 1
+        d.a_kmajor, d.b_kmajor = 0, 0
+        d.in_dtype, d.out_dtype = BF16, F32
+        d.act, d.accumulate, d.split_k = ACT_NONE, int(acc), 0
+        d.alpha, d.dropout_p, d.dropout_seed = 1.0, 0.0, 0
+    if GEMM_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _abi.lib().favit_gemm_grouped_tn(arr, n, _st())
+    if rc == -2:
+        return False
+    _abi.check(rc, "favit_gemm_grouped_tn")
+    if GEMM_TRACE is not None:
+        e1.record()
+        fl = sum(2.0 * p[0].shape[0] * p[0].shape[1] * p[1].shape[1] for p in problems)
+        GEMM_TRACE.append((e0, e1, fl, "bf16_MM_of32_grouped", (len(problems),)))
+    return True
+
+
 def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     require_gpu(src)
     src = src.contiguous()

@@ -91,6 +91,13 @@ typedef struct favit_gemm_t {
 
 int favit_gemm(const favit_gemm_t* g, void* stream);
 
+/* Grouped weight-gradient GEMMs: `count` (<= 8) problems dW_i = dY_i^T . X_i that share the token
+ * dimension K (e.g. the four nn.Linear layers of one transformer block) as ONE launch.  Every
+ * problem must be bf16 in / fp32 out with a_kmajor = b_kmajor = 0, no epilogue other than
+ * a_rowsum (bias gradient) and accumulate; returns FAVIT_ERR_UNSUPPORTED otherwise (the caller
+ * then issues them one by one). */
+int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void* stream);
+
 /* dst[i] = (dst_dtype) src[i] */
 int favit_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 
