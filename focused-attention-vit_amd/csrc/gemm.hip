@@ -843,8 +843,8 @@ __device__ __forceinline__ void store16_policy(void* ptr, uint4 v, int policy) {
 constexpr int WEPI_LD = 68;                         // padded fp32 row
 constexpr int WEPI_BYTES = 32 * WEPI_LD * 4;        // 8704 B per wave
 
-template <typename InT, typename OutT, int half>
-__device__ __forceinline__ void wave_epilogue_half(const KParams& p, const f32x4 (&acc)[4][4], OutT* C, long mbase,
+template <typename InT, typename OutT, int half, int NJ = 4, int CB = 0>
+__device__ __forceinline__ void wave_epilogue_half(const KParams& p, const f32x4 (&acc)[4][NJ], OutT* C, long mbase,
                                               long nbase, int lane, float* wl, bool first_split) {
   const bool fast = p.c_vec && (nbase + 64 <= p.N);
   {
@@ -852,7 +852,7 @@ __device__ __forceinline__ void wave_epilogue_half(const KParams& p, const f32x4
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4*>(wl + (ii * 16 + (lane & 15)) * WEPI_LD + j * 16 + 4 * (lane >> 4)) = acc[half * 2 + ii][j];
+        *reinterpret_cast<f32x4*>(wl + (ii * 16 + (lane & 15)) * WEPI_LD + j * 16 + 4 * (lane >> 4)) = acc[half * 2 + ii][CB * 4 + j];
     // (same wave wrote and reads: the compiler's lgkmcnt wait orders them; no barrier needed)
     bool done = false;
     if constexpr (sizeof(OutT) == 4) {
