@@ -193,8 +193,14 @@ def main():
             sec, fl, n = fam[dom]
             peak = BF16_DENSE_PEAK_TFLOPS if dom.startswith("bf16") else F32_MFMA_PEAK_TFLOPS
             ach = fl / sec / 1e12
+            traffic = None           # HBM bytes per launch from the committed PMC passes (profiles/)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+                    traffic = json.load(f)["families"][dom]["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(ach / peak, 4), "traffic": None,
+                               "frac": round(ach / peak, 4), "traffic": traffic,
                                "kernel": f"gemm_{dom}", "launches": n, "avg_launch_us": round(1e6 * sec / n, 2),
                                "avg_flops_per_launch": round(fl / n, 1)}
             tot = sum(v[0] for v in fam.values())
