@@ -12,6 +12,7 @@
 //    Backward recomputes the probabilities; dK~/dV~ are gathered per key row from LDS
 //    tables of dS / P (deterministic, no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -423,6 +424,152 @@ __global__ __launch_bounds__(256) void mhla_bwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
+// MFMA formulation of the banded attention core (bf16, hd in {32, 64, 128}, W <= 15).
+// A wave owns 16 query rows.  Their extended key set -- the 16+2h band keys plus the two wrap keys
+// 0 and L-1 that the pad rule can reference -- fits 32 "slots", so
+//   S[slot][q]  = K_slots . Q^T      (v_mfma_f32_16x16x32_bf16, 2 key tiles x hd/32 k-steps)
+//   O^T[d][q]   = V_slots^T . P      (hd/16 MFMAs, K = 32 slots, V^T fragments by ds_read_b64_tr_b16)
+// replace ~2*W*hd scalar FMAs per query.  The window rule (duplicates included) becomes a per-slot
+// multiplicity: band slots count 1, the wrap slots count the number of pad copies of that row;
+// softmax weights are mult*exp(s - max).  The lane that holds S[slot 4g+r][query] after the first
+// MFMA also holds exactly the P element the second MFMA wants as its B operand (same permuted slot
+// order on both operands), so P never leaves registers.
+// ---------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr_t;
+
+struct SlotInfo {          // per lane: the slot geometry of one query row
+  int i, lo, hi, n, pad, end_pad, front_pad;
+  __device__ __forceinline__ void init(int row, int L, int W, int h) {
+    i = row;
+    lo = max(0, i - h);
+    hi = min(L, i + h + 1);
+    n = hi - lo;
+    pad = W - n;
+    end_pad = (lo == 0) ? pad : 0;
+    front_pad = (lo > 0) ? pad : 0;
+  }
+};
+
+// key index of a slot for the tile that starts at query row t0 (clamped into [0, L-1])
+__device__ __forceinline__ int slot_key(int slot, int t0, int h, int L) {
+  int j;
+  if (slot == 31) j = L - 1;
+  else if (slot >= 16 + 2 * h) j = 0;                  // wrap slot 30 and the unused slots: any staged, finite row
+  else j = t0 - h + slot;
+  return min(max(j, 0), L - 1);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = HD * 2 + 16;                      // padded row: conflict-free fragment reads
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, qi = lane & 15;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int r0 = blockIdx.x * 64, r1 = min(a.L, r0 + 64);
+  const int L = a.L, W = a.W, h = W >> 1, D = a.H * HD;
+  const long ld = 3L * D, tok0 = (long)b * L;
+  const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
+
+  RowImage im;
+  im.init(r0 - h, r1 + h, 1, L);
+  char* ldsK = smem;
+  char* ldsV = smem + im.n_rows * RS;
+  stage_rows<bf16_t>(ldsK, im, qkv, ld, tok0, D + head * HD, HD, RS, tid, 256);
+  stage_rows<bf16_t>(ldsV, im, qkv, ld, tok0, 2 * D + head * HD, HD, RS, tid, 256);
+  __syncthreads();
+
+  const int t0 = r0 + 16 * wave;
+  if (t0 >= r1) return;                                // whole wave idle (no barrier after this point)
+  const int i = t0 + qi;
+  const bool qvalid = i < L;
+  SlotInfo si;
+  si.init(min(i, L - 1), L, W, h);
+
+  // ---- S = K_slots . Q^T ----
+  const bf16_t* qrow = qkv + (tok0 + si.i) * ld + head * HD;
+  f32x4 S[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  const int krow0 = im.slot(slot_key(qi, t0, h, L)), krow1 = im.slot(slot_key(16 + qi, t0, h, L));
+#pragma unroll
+  for (int ks = 0; ks < HD / 32; ++ks) {
+    const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qrow + 32 * ks + 8 * g);
+    const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(ldsK + krow0 * RS + (32 * ks + 8 * g) * 2);
+    const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(ldsK + krow1 * RS + (32 * ks + 8 * g) * 2);
+    S[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, S[0], 0, 0, 0);
+    S[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, S[1], 0, 0, 0);
+  }
+
+  // ---- per-slot multiplicity, mask, softmax (lane holds slots 16kt + 4g + r of query qi) ----
+  const float inv_sq = 1.0f / sqrtf((float)HD);
+  float sc[8], mult[8], kw[8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int kt = e >> 2, r = e & 3;
+    const int slot = 16 * kt + 4 * g + r;
+    int j, mu, w0;                                      // key, multiplicity, first window index
+    if (slot < 16 + 2 * h && slot < 30) {
+      j = t0 - h + slot;
+      mu = (j >= si.lo && j < si.hi) ? 1 : 0;
+      w0 = (si.lo == 0 || si.pad == 0) ? (j - si.lo) : si.pad + (j - si.lo);
+    } else if (slot == 30) {
+      j = 0; mu = si.front_pad; w0 = 0;
+    } else if (slot == 31) {
+      j = L - 1; mu = si.end_pad; w0 = si.n;
+    } else {
+      j = 0; mu = 0; w0 = 0;
+    }
+    if (mu > 0 && a.mask && a.mask[((long)b * L + si.i) * L + j] == 0) mu = 0;     // mhla.py:143
+    float kwe = (float)mu;
+    if (a.thresh && mu > 0) {                            // dropout acts on every window copy separately
+      kwe = 0.f;
+      for (int c = 0; c < mu; ++c) {
+        const uint64_t idx = (((uint64_t)b * a.H + head) * L + si.i) * W + (w0 + c);
+        kwe += favit_keep(a.seed, idx, a.thresh) ? a.keep_scale : 0.f;
+      }
+    }
+    sc[e] = S[kt][r] * inv_sq;
+    mult[e] = (float)mu;
+    kw[e] = kwe;
+    if (mu > 0) mx = fmaxf(mx, sc[e]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float lsum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = (mult[e] > 0.f) ? __expf(sc[e] - mx) : 0.f;
+    lsum = fmaf(mult[e], sc[e], lsum);
+  }
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  const float inv_l = 1.0f / lsum;
+  bf16x8 pf;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)(sc[e] * inv_l * kw[e]);
+
+  // ---- O^T = V_slots^T . P ----
+  const int q4 = qi >> 2, p4 = qi & 3;
+  const int vrow0 = im.slot(slot_key(4 * g + q4, t0, h, L)), vrow1 = im.slot(slot_key(16 + 4 * g + q4, t0, h, L));
+  bf16_t* orow = reinterpret_cast<bf16_t*>(a.out) + (tok0 + si.i) * (long)D + head * HD;
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) {
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsV + vrow0 * RS + (16 * dt + 4 * p4) * 2));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsV + vrow1 * RS + (16 * dt + 4 * p4) * 2));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 vv;
+    vv[0] = lo4[0]; vv[1] = lo4[1]; vv[2] = lo4[2]; vv[3] = lo4[3];
+    vv[4] = hi4[0]; vv[5] = hi4[1]; vv[6] = hi4[2]; vv[7] = hi4[3];
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o, 0, 0, 0);
+    if (qvalid) {
+      bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+      *reinterpret_cast<bf16x4*>(orow + 16 * dt + 4 * g) = ob;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // latent_proj fold (weight space, tiny): LDS-tiled, register-blocked small GEMMs so each launch is
 // a few microseconds.
 //   Weff[s,h] = Wl . Wqkv[s,h],  beff[s,h] = Wl . bqkv[s,h] + bl      (s in {k, v})
@@ -628,6 +775,16 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
   a.keep_scale = 1.0f / (1.0f - p);
   a.seed = seed;
   hipStream_t st = as_stream(stream);
+  if (!bwd && dtype == FAVIT_BF16 && (hd == 32 || hd == 64 || hd == 128) && getenv("FAVIT_MHLA_VALU") == nullptr) {
+    const int h = W / 2;
+    const size_t lds = (size_t)2 * (64 + 2 * h + 2) * (hd * 2 + 16);
+    dim3 grid((L + 63) / 64, H, B);
+    if (hd == 32) hipLaunchKernelGGL(mhla_fwd_mfma_kernel<32>, grid, dim3(256), lds, st, a);
+    else if (hd == 64) hipLaunchKernelGGL(mhla_fwd_mfma_kernel<64>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(mhla_fwd_mfma_kernel<128>, grid, dim3(256), lds, st, a);
+    FAVIT_CHECK_LAUNCH();
+    return FAVIT_OK;
+  }
   if (dtype == FAVIT_F32) return W <= 7 ? dispatch_dpl<float, 7>(bwd, a, st) : dispatch_dpl<float, 15>(bwd, a, st);
   if (dtype == FAVIT_BF16) return W <= 7 ? dispatch_dpl<bf16_t, 7>(bwd, a, st) : dispatch_dpl<bf16_t, 15>(bwd, a, st);
   return FAVIT_ERR_INVALID;
