@@ -151,6 +151,14 @@ struct RowImage {
     if (r < head_n) return n_main + r;
     return n_main + head_n + (r - tail_lo);
   }
+  // like slot(), but rows that are not staged at all map to the nearest staged main row (used for
+  // slots whose result is discarded, so that no uninitialised LDS is ever read)
+  __device__ __forceinline__ int slot_safe(int r) const {
+    if (r >= main_lo && r < main_hi) return r - main_lo;
+    if (r < head_n) return n_main + r;
+    if (r >= tail_lo) return n_main + head_n + (r - tail_lo);
+    return (r < main_lo ? 0 : n_main - 1);
+  }
   __device__ __forceinline__ int row_of_slot(int s) const {
     if (s < n_main) return main_lo + s;
     if (s < n_main + head_n) return s - n_main;
@@ -177,6 +185,37 @@ __device__ __forceinline__ void stage_rows(char* lds, const RowImage& im, const 
   }
 }
 
+// Two-phase staging: ALL global loads of a thread are issued (into registers) before the first LDS
+// store, so their latencies overlap; the single-loop stage_rows() above made every 16-byte chunk
+// wait for its own load (vmcnt(0) per iteration) and dominated the workgroup's lifetime.
+template <typename T, int NCH>
+struct RowStager {
+  uint4 regs[NCH];
+  template <typename F>
+  __device__ __forceinline__ void load(int nrows, const T* src, long ld, long tok0, int col0, int hd, int tid, F row_of) {
+    const int cpr = hd * (int)sizeof(T) / 16;
+    const int total = nrows * cpr;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int c = min(tid + 256 * it, total - 1);      // clamped: unconditional load, store is predicated
+      const int s = c / cpr, ch = c - s * cpr;
+      regs[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(src + (tok0 + row_of(s)) * ld + col0) + ch * 16);
+    }
+  }
+  __device__ __forceinline__ void store(char* lds, int nrows, int hd, int rs, int tid) const {
+    const int cpr = hd * (int)sizeof(T) / 16;
+    const int total = nrows * cpr;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int c = tid + 256 * it;
+      if (c < total) {
+        const int s = c / cpr, ch = c - s * cpr;
+        *reinterpret_cast<uint4*>(lds + s * rs + ch * 16) = regs[it];
+      }
+    }
+  }
+};
+
 struct AttnArgs {
   const void* qkv;
   const void* dout;
@@ -184,6 +223,7 @@ struct AttnArgs {
   const uint8_t* mask;
   int B, L, H, hd, W;
   int rb;              // backward: key/query rows per workgroup (32 - 2h keeps phase 1 to one pass)
+  int dbg;             // experiments only (FAVIT_MHLA_DBG)
   float inv_sqrt_hd;   // unused (true division is applied), kept for clarity
   uint32_t thresh;
   float keep_scale;
@@ -242,8 +282,15 @@ __global__ __launch_bounds__(256) void mhla_fwd_kernel(AttnArgs a) {
   im.init(r0 - h, r1 + h, 1, a.L);     // forward only needs keys 0 and L-1 outside the band
   char* ldsK = smem;
   char* ldsV = smem + im.n_rows * rs;
-  stage_rows<T>(ldsK, im, qkv, ld, tok0, D + head * HD, HD, rs, tid, 256);
-  stage_rows<T>(ldsV, im, qkv, ld, tok0, 2 * D + head * HD, HD, rs, tid, 256);
+  {
+    constexpr int NCH = ((FWD_QPB + 16) * (HD * (int)sizeof(T) / 16) + 255) / 256;
+    RowStager<T, NCH> sk, sv;
+    auto rowf = [&](int s) { return im.row_of_slot(s); };
+    sk.load(im.n_rows, qkv, ld, tok0, D + head * HD, HD, tid, rowf);
+    sv.load(im.n_rows, qkv, ld, tok0, 2 * D + head * HD, HD, tid, rowf);
+    sk.store(ldsK, im.n_rows, HD, rs, tid);
+    sv.store(ldsV, im.n_rows, HD, rs, tid);
+  }
   __syncthreads();
 
   for (int base = r0; base < r1; base += 32) {
@@ -309,18 +356,21 @@ __global__ __launch_bounds__(256) void mhla_bwd_kernel(AttnArgs a) {
   float* tds = reinterpret_cast<float*>(ldsG + 64 * rs);     // [64][WMAX] dS / sqrt(hd)
   float* tp = tds + 64 * WMAX;                               // [64][WMAX] P after dropout
 
-  stage_rows<T>(ldsK, imK, qkv, ld, tok0, D + head * HD, HD, rs, tid, 256);
-  stage_rows<T>(ldsV, imK, qkv, ld, tok0, 2 * D + head * HD, HD, rs, tid, 256);
   {
-    const int cpr = HD * (int)sizeof(T) / 16;
-    for (int c = tid; c < n_q * cpr; c += 256) {
-      const int s = c / cpr, ch = c - s * cpr;
-      const int r = qrow_of(s);
-      *reinterpret_cast<uint4*>(ldsQ + s * rs + ch * 16) =
-          *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(qkv + (tok0 + r) * ld + head * HD) + ch * 16);
-      *reinterpret_cast<uint4*>(ldsG + s * rs + ch * 16) =
-          *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(dout + (tok0 + r) * (long)D + head * HD) + ch * 16);
-    }
+    constexpr int CPR = HD * (int)sizeof(T) / 16;
+    constexpr int NKV = (80 * CPR + 255) / 256, NQ = (64 * CPR + 255) / 256;
+    RowStager<T, NKV> sk, sv;
+    RowStager<T, NQ> sq, sg;
+    auto rowk = [&](int s) { return imK.row_of_slot(s); };
+    auto rowq = [&](int s) { return qrow_of(s); };
+    sk.load(imK.n_rows, qkv, ld, tok0, D + head * HD, HD, tid, rowk);
+    sv.load(imK.n_rows, qkv, ld, tok0, 2 * D + head * HD, HD, tid, rowk);
+    sq.load(n_q, qkv, ld, tok0, head * HD, HD, tid, rowq);
+    sg.load(n_q, dout, (long)D, tok0, head * HD, HD, tid, rowq);
+    sk.store(ldsK, imK.n_rows, HD, rs, tid);
+    sv.store(ldsV, imK.n_rows, HD, rs, tid);
+    sq.store(ldsQ, n_q, HD, rs, tid);
+    sg.store(ldsG, n_q, HD, rs, tid);
   }
   __syncthreads();
 
@@ -475,10 +525,18 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
   im.init(r0 - h, r1 + h, 1, L);
   char* ldsK = smem;
   char* ldsV = smem + im.n_rows * RS;
-  stage_rows<bf16_t>(ldsK, im, qkv, ld, tok0, D + head * HD, HD, RS, tid, 256);
-  stage_rows<bf16_t>(ldsV, im, qkv, ld, tok0, 2 * D + head * HD, HD, RS, tid, 256);
+  {
+    constexpr int NCH = (80 * (HD * 2 / 16) + 255) / 256;
+    RowStager<bf16_t, NCH> sk, sv;
+    auto rowf = [&](int s) { return im.row_of_slot(s); };
+    sk.load(im.n_rows, qkv, ld, tok0, D + head * HD, HD, tid, rowf);
+    sv.load(im.n_rows, qkv, ld, tok0, 2 * D + head * HD, HD, tid, rowf);
+    sk.store(ldsK, im.n_rows, HD, RS, tid);
+    sv.store(ldsV, im.n_rows, HD, RS, tid);
+  }
   __syncthreads();
 
+  if (a.dbg == 1) return;
   const int t0 = r0 + 16 * wave;
   if (t0 >= r1) return;                                // whole wave idle (no barrier after this point)
   const int i = t0 + qi;
@@ -562,9 +620,268 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
     vv[4] = hi4[0]; vv[5] = hi4[1]; vv[6] = hi4[2]; vv[7] = hi4[3];
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o, 0, 0, 0);
-    if (qvalid) {
+    if (qvalid && (a.dbg != 2 || o[0] == 12345.f)) {
       bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
       *reinterpret_cast<bf16x4*>(orow + 16 * dt + 4 * g) = ob;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// MFMA backward (bf16, hd in {32,64,128}; W <= 7, or W <= 11 when L > 16).
+// Phase 1 (query tiles of 16 rows, recomputed like the forward): S, P, dP = V.dO^T, dS, and
+//   dQ^T = K_slots^T . dS; dS and the dropped probabilities go to LDS tables [query][32 slots].
+// Phase 2 (key tiles of 16 rows owned by this workgroup): every key gathers its column of the
+//   tables over the 16+2h band queries (+ the wrap rows for keys 0 / L-1) into a B fragment and
+//   dK^T = Q^T . W_dS, dV^T = dO^T . W_P run on MFMA with Q^T / dO^T fragments read by
+//   ds_read_b64_tr_b16.  No atomics: halo query rows are recomputed (deterministic).
+// ---------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void mhla_bwd_mfma_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = HD * 2 + 16;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, qi = lane & 15, q4 = qi >> 2, p4 = qi & 3;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int r0 = blockIdx.x * 64, r1 = min(a.L, r0 + 64);
+  const int L = a.L, W = a.W, h = W >> 1, D = a.H * HD;
+  const long ld = 3L * D, tok0 = (long)b * L;
+  const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
+  const bf16_t* dout = reinterpret_cast<const bf16_t*>(a.dout);
+  bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.out);
+
+  // query tiles: main rows [qm_lo, qm_hi) in tiles of 16, then (if this block owns key L-1) the rows
+  // 0.. that END-pad onto it, then (if it owns key 0) the rows tx_lo.. that FRONT-pad onto it
+  const int qm_lo = max(0, r0 - h), qm_hi = min(L, r1 + h);
+  const int nmt = (qm_hi - qm_lo + 15) >> 4;
+  const int has_hx = (r1 >= L) ? 1 : 0;
+  const int tx_lo = max(h + 1, L - h);
+  const int has_tx = (r0 == 0 && tx_lo < L) ? 1 : 0;
+  const int ntiles = nmt + has_hx + has_tx;
+  auto tile_t0 = [&](int t) { return t < nmt ? qm_lo + 16 * t : ((has_hx && t == nmt) ? 0 : tx_lo); };
+  // table / Q-image slot of query row i for the band (main) part
+  auto main_slot = [&](int i) { return min(max(i, qm_lo), qm_hi - 1) - qm_lo; };
+  auto row_slot = [&](int i, bool head_kind) {           // slot of a wrap row
+    if (i >= qm_lo && i < qm_hi) return i - qm_lo;
+    return head_kind ? 16 * nmt + i : 16 * (nmt + has_hx) + (i - tx_lo);
+  };
+
+  RowImage imK;
+  imK.init(r0 - 2 * h, r1 + 2 * h, 2 * h + 1, L);
+  char* ldsK = smem;
+  char* ldsV = ldsK + imK.n_rows * RS;
+  char* ldsQ = ldsV + imK.n_rows * RS;
+  char* ldsG = ldsQ + 16 * ntiles * RS;
+  bf16_t* tds = reinterpret_cast<bf16_t*>(ldsG + 16 * ntiles * RS);      // [16*ntiles][32]
+  bf16_t* tp = tds + 16 * ntiles * 32;
+
+  {
+    constexpr int CPR = HD * 2 / 16;
+    constexpr int NKV = (108 * CPR + 255) / 256, NQ = (112 * CPR + 255) / 256;
+    RowStager<bf16_t, NKV> sk, sv;
+    RowStager<bf16_t, NQ> sq, sg;
+    auto rowk = [&](int s) { return imK.row_of_slot(s); };
+    auto rowq = [&](int s) { return min(tile_t0(s >> 4) + (s & 15), L - 1); };
+    sk.load(imK.n_rows, qkv, ld, tok0, D + head * HD, HD, tid, rowk);
+    sv.load(imK.n_rows, qkv, ld, tok0, 2 * D + head * HD, HD, tid, rowk);
+    sq.load(16 * ntiles, qkv, ld, tok0, head * HD, HD, tid, rowq);
+    sg.load(16 * ntiles, dout, (long)D, tok0, head * HD, HD, tid, rowq);
+    sk.store(ldsK, imK.n_rows, HD, RS, tid);
+    sv.store(ldsV, imK.n_rows, HD, RS, tid);
+    sq.store(ldsQ, 16 * ntiles, HD, RS, tid);
+    sg.store(ldsG, 16 * ntiles, HD, RS, tid);
+  }
+  __syncthreads();
+
+  const float inv_sq = 1.0f / sqrtf((float)HD);
+  // ---------------- phase 1: query tiles ----------------
+  for (int tile = wave; tile < ntiles; tile += 4) {
+    const int t0 = tile_t0(tile);
+    const int i = t0 + qi;
+    SlotInfo si;
+    si.init(min(i, L - 1), L, W, h);
+    const int krow0 = imK.slot_safe(slot_key(qi, t0, h, L)), krow1 = imK.slot_safe(slot_key(16 + qi, t0, h, L));
+    const char* qimg = ldsQ + (16 * tile + qi) * RS;
+    const char* gimg = ldsG + (16 * tile + qi) * RS;
+    f32x4 S[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 dP[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      const int off = (32 * ks + 8 * g) * 2;
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qimg + off);
+      const bf16x8 gf = *reinterpret_cast<const bf16x8*>(gimg + off);
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(ldsK + krow0 * RS + off);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(ldsK + krow1 * RS + off);
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(ldsV + krow0 * RS + off);
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(ldsV + krow1 * RS + off);
+      S[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, S[0], 0, 0, 0);
+      S[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, S[1], 0, 0, 0);
+      dP[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, gf, dP[0], 0, 0, 0);
+      dP[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, gf, dP[1], 0, 0, 0);
+    }
+    float sc[8], mult[8], kw[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kt = e >> 2, r = e & 3;
+      const int slot = 16 * kt + 4 * g + r;
+      int j, mu, w0;
+      if (slot < 16 + 2 * h && slot < 30) {
+        j = t0 - h + slot;
+        mu = (j >= si.lo && j < si.hi) ? 1 : 0;
+        w0 = (si.lo == 0 || si.pad == 0) ? (j - si.lo) : si.pad + (j - si.lo);
+      } else if (slot == 30) {
+        j = 0; mu = si.front_pad; w0 = 0;
+      } else if (slot == 31) {
+        j = L - 1; mu = si.end_pad; w0 = si.n;
+      } else {
+        j = 0; mu = 0; w0 = 0;
+      }
+      if (mu > 0 && a.mask && a.mask[((long)b * L + si.i) * L + j] == 0) mu = 0;
+      float kwe = (float)mu;
+      if (a.thresh && mu > 0) {
+        kwe = 0.f;
+        for (int c = 0; c < mu; ++c) {
+          const uint64_t idx = (((uint64_t)b * a.H + head) * L + si.i) * W + (w0 + c);
+          kwe += favit_keep(a.seed, idx, a.thresh) ? a.keep_scale : 0.f;
+        }
+      }
+      sc[e] = S[kt][r] * inv_sq;
+      mult[e] = (float)mu;
+      kw[e] = kwe;
+      if (mu > 0) mx = fmaxf(mx, sc[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float lsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = (mult[e] > 0.f) ? __expf(sc[e] - mx) : 0.f;
+      lsum = fmaf(mult[e], sc[e], lsum);
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv_l = 1.0f / lsum;
+    float dot = 0.f;
+    float dpn[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] *= inv_l;                                   // pn
+      dpn[e] = kw[e] * dP[e >> 2][e & 3];
+      dot = fmaf(sc[e], dpn[e], dot);
+    }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    bf16x8 dsf;
+    bf16x4 pw0, pw1, ds0, ds1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float ds = (sc[e] * dpn[e] - mult[e] * sc[e] * dot) * inv_sq;
+      const bf16_t dsb = (bf16_t)ds, pwb = (bf16_t)(sc[e] * kw[e]);
+      dsf[e] = dsb;
+      if (e < 4) { ds0[e] = dsb; pw0[e] = pwb; } else { ds1[e - 4] = dsb; pw1[e - 4] = pwb; }
+    }
+    {
+      bf16_t* trow = tds + (16 * tile + qi) * 32 + 4 * g;
+      bf16_t* prow = tp + (16 * tile + qi) * 32 + 4 * g;
+      *reinterpret_cast<bf16x4*>(trow) = ds0;
+      *reinterpret_cast<bf16x4*>(trow + 16) = ds1;
+      *reinterpret_cast<bf16x4*>(prow) = pw0;
+      *reinterpret_cast<bf16x4*>(prow + 16) = pw1;
+    }
+    // dQ^T = K_slots^T . dS  (only rows this block owns; main tiles only)
+    const bool own = tile < nmt && i >= r0 && i < r1;
+    const int vrow0 = imK.slot_safe(slot_key(4 * g + q4, t0, h, L)), vrow1 = imK.slot_safe(slot_key(16 + 4 * g + q4, t0, h, L));
+    bf16_t* dqrow = dqkv + (tok0 + si.i) * ld + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + vrow0 * RS + (16 * dt + 4 * p4) * 2));
+      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + vrow1 * RS + (16 * dt + 4 * p4) * 2));
+      s16x8 kk;
+      kk[0] = lo4[0]; kk[1] = lo4[1]; kk[2] = lo4[2]; kk[3] = lo4[3];
+      kk[4] = hi4[0]; kk[5] = hi4[1]; kk[6] = hi4[2]; kk[7] = hi4[3];
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kk), dsf, o, 0, 0, 0);
+      if (own) {
+        bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+        *reinterpret_cast<bf16x4*>(dqrow + 16 * dt + 4 * g) = ob;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase 2: key tiles ----------------
+  const int k0 = r0 + 16 * wave;
+  if (k0 >= r1) return;
+  const int j = k0 + qi;                                  // this lane's key (B-operand column)
+  const bool has0 = (k0 == 0), hasL = (L - 1 >= k0 && L - 1 < k0 + 16);
+  const int nband = 16 + 2 * h;
+  const int nhx = hasL ? min(h, L - 1) + 1 : 0;           // rows 0..min(h,L-1) END-pad onto key L-1
+  // q-slot -> (query row, table slot, kind): kind 0 band, 1 END-pad row (key L-1), 2 FRONT-pad row (key 0)
+  auto qs_row = [&](int qs, int& row, int& tslot, int& kind) {
+    if (qs < nband) {
+      kind = 0;
+      row = k0 - h + qs;
+      tslot = main_slot(row);
+    } else if (qs < nband + nhx) {
+      kind = 1;
+      row = qs - nband;
+      tslot = row_slot(row, true);
+    } else {
+      kind = 2;
+      row = tx_lo + (qs - nband - nhx);
+      if (!has0 || row >= L) { kind = 3; row = 0; tslot = main_slot(k0); return; }
+      tslot = row_slot(row, false);
+    }
+  };
+  // B fragments: lane = key j, 8 q-slots 8g..8g+7
+  bf16x8 wds, wp;
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    int row, tslot, kind;
+    qs_row(8 * g + jj, row, tslot, kind);
+    bf16_t vds = (bf16_t)0.f, vp = (bf16_t)0.f;
+    if (kind == 0) {
+      if (row >= 0 && row < L && j < L && abs(row - j) <= h) {
+        const int t0i = qm_lo + 16 * ((row - qm_lo) >> 4);
+        const int sl = j - t0i + h;
+        vds = tds[tslot * 32 + sl];
+        vp = tp[tslot * 32 + sl];
+      }
+    } else if (kind == 1) {
+      if (j == L - 1) { vds = tds[tslot * 32 + 31]; vp = tp[tslot * 32 + 31]; }
+    } else if (kind == 2) {
+      if (j == 0 && L > 1) { vds = tds[tslot * 32 + 30]; vp = tp[tslot * 32 + 30]; }
+    }
+    wds[jj] = vds;
+    wp[jj] = vp;
+  }
+  // A fragments: Q^T / dO^T rows of q-slots 8g+q4 and 8g+4+q4 (every lane supplies one row address)
+  int ra, rb_, ta, tb, ka, kb;
+  qs_row(8 * g + q4, ra, ta, ka);
+  qs_row(8 * g + 4 + q4, rb_, tb, kb);
+  const bool jvalid = j < r1;
+  bf16_t* dkrow = dqkv + (tok0 + min(j, L - 1)) * ld + D + head * HD;
+  bf16_t* dvrow = dkrow + D;
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) {
+    const int coff = (16 * dt + 4 * p4) * 2;
+    const s16x4 qa = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsQ + ta * RS + coff));
+    const s16x4 qb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsQ + tb * RS + coff));
+    const s16x4 ga = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsG + ta * RS + coff));
+    const s16x4 gb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsG + tb * RS + coff));
+    s16x8 qq, gg;
+    qq[0] = qa[0]; qq[1] = qa[1]; qq[2] = qa[2]; qq[3] = qa[3]; qq[4] = qb[0]; qq[5] = qb[1]; qq[6] = qb[2]; qq[7] = qb[3];
+    gg[0] = ga[0]; gg[1] = ga[1]; gg[2] = ga[2]; gg[3] = ga[3]; gg[4] = gb[0]; gg[5] = gb[1]; gg[6] = gb[2]; gg[7] = gb[3];
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qq), wds, dk, 0, 0, 0);
+    dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gg), wp, dv, 0, 0, 0);
+    if (jvalid) {
+      bf16x4 kb4 = {(bf16_t)dk[0], (bf16_t)dk[1], (bf16_t)dk[2], (bf16_t)dk[3]};
+      bf16x4 vb4 = {(bf16_t)dv[0], (bf16_t)dv[1], (bf16_t)dv[2], (bf16_t)dv[3]};
+      *reinterpret_cast<bf16x4*>(dkrow + 16 * dt + 4 * g) = kb4;
+      *reinterpret_cast<bf16x4*>(dvrow + 16 * dt + 4 * g) = vb4;
     }
   }
 }
@@ -770,6 +1087,7 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
   a.qkv = qkv; a.dout = dout; a.out = out; a.mask = mask;
   a.B = B; a.L = L; a.H = H; a.hd = hd; a.W = W;
   a.rb = BWD_RB - 2 * (W / 2);
+  { const char* e = getenv("FAVIT_MHLA_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.inv_sqrt_hd = 0.f;
   a.thresh = dropout_threshold(p);
   a.keep_scale = 1.0f / (1.0f - p);
@@ -784,6 +1102,32 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
     else hipLaunchKernelGGL(mhla_fwd_mfma_kernel<128>, grid, dim3(256), lds, st, a);
     FAVIT_CHECK_LAUNCH();
     return FAVIT_OK;
+  }
+  // The MFMA backward is correct (same tests as the default path) but measured slower than the
+  // 8-lanes-per-row kernel at the bench shape (189 vs 150 us: 72 KiB of LDS allow only two
+  // workgroups per CU and every phase is latency-bound), so it is opt-in: FAVIT_MHLA_BWD_MFMA=1.
+  if (bwd && dtype == FAVIT_BF16 && (hd == 32 || hd == 64 || hd == 128) && (W <= 7 || (W <= 11 && L > 16)) &&
+      getenv("FAVIT_MHLA_BWD_MFMA") != nullptr && getenv("FAVIT_MHLA_VALU") == nullptr) {
+    const int h = W / 2;
+    const int rs = hd * 2 + 16;
+    const int krows = (64 + 4 * h) + 2 * (2 * h + 1);
+    const int ntl = (64 + 2 * h + 15) / 16 + 2;
+    const size_t lds = (size_t)2 * krows * rs + (size_t)2 * 16 * ntl * rs + (size_t)2 * 16 * ntl * 32 * 2;
+    if (lds <= 160 * 1024) {
+      dim3 grid((L + 63) / 64, H, B);
+      if (hd == 32) {
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mhla_bwd_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(mhla_bwd_mfma_kernel<32>, grid, dim3(256), lds, st, a);
+      } else if (hd == 64) {
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mhla_bwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(mhla_bwd_mfma_kernel<64>, grid, dim3(256), lds, st, a);
+      } else {
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mhla_bwd_mfma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(mhla_bwd_mfma_kernel<128>, grid, dim3(256), lds, st, a);
+      }
+      FAVIT_CHECK_LAUNCH();
+      return FAVIT_OK;
+    }
   }
   if (dtype == FAVIT_F32) return W <= 7 ? dispatch_dpl<float, 7>(bwd, a, st) : dispatch_dpl<float, 15>(bwd, a, st);
   if (dtype == FAVIT_BF16) return W <= 7 ? dispatch_dpl<bf16_t, 7>(bwd, a, st) : dispatch_dpl<bf16_t, 15>(bwd, a, st);

@@ -183,10 +183,15 @@ def test_embed_prologue(K):
                                            (17, 5, 32, True), (65, 7, 64, False), (197, 7, 64, False),
                                            (197, 15, 16, False), (33, 9, 128, False), (64, 7, 64, False),
                                            (100, 3, 64, True)])
-def test_mhla_core_fwd_bwd_vs_window_gather(K, dtype, L, W, hd, masked):
+@pytest.mark.parametrize("bwd_mfma", [False, True])
+def test_mhla_core_fwd_bwd_vs_window_gather(K, dtype, L, W, hd, masked, bwd_mfma, monkeypatch):
     """The attention core against a direct restatement of the reference's gather-based windows
     (duplicated pad indices take part in the softmax, models/mhla.py:117-154)."""
     from oracle import favit_oracle as O
+    if bwd_mfma:
+        if dtype != torch.bfloat16 or hd < 32:
+            pytest.skip("the MFMA backward exists for bf16, hd >= 32")
+        monkeypatch.setenv("FAVIT_MHLA_BWD_MFMA", "1")      # read by the library at call time
     B, H = 2, 3
     D = H * hd
     g = torch.Generator(device=DEV).manual_seed(L * 31 + W)
