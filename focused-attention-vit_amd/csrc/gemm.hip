@@ -2,9 +2,15 @@
 //
 //   C[m,n] = epilogue( alpha * sum_k A[m,k] * B[n,k] )
 //
-// One 256-thread workgroup (4 waves, 2x2) owns a 128x128 output tile; each wave owns a
-// 64x64 sub-tile.  Operands are staged global -> registers -> LDS (double buffered, one
-// barrier per K-step) and consumed from LDS as MFMA fragments:
+// Three bf16 kernels share the fragment / epilogue code below:
+//   * "p4" (the hot one): 256x128 tile, 8 waves, BK = 32, three LDS stages filled by
+//     global_load_lds with a counted vmcnt, wave-private transpose epilogue, 2 workgroups per CU;
+//     also runs the grouped / XCD-affine split-K weight-gradient launch
+//   * "glds": 128x128 tile, direct-to-LDS double buffer (small and batched problems)
+//   * the register-staged 128x128 kernel (any shape / alignment; the fallback)
+// and one exact-fp32 kernel (the parity mode).  In the 128x128 kernels a 256-thread workgroup
+// (4 waves, 2x2) owns the tile, each wave a 64x64 sub-tile; operands are consumed from LDS as
+// MFMA fragments:
 //   bf16 : v_mfma_f32_16x16x32_bf16, BK = 64.
 //          k-major operand  -> LDS image [row][64] (128-B rows), 16-B chunk XOR swizzle,
 //                              fragment = one ds_read_b128
@@ -541,157 +547,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_glds_kernel(KParams p) {
 }
 
 // --------------------------------------------------------------------------------------
-// bf16 kernel, 256x128 tile, 8 waves (4x2, 64x64 each), THREE LDS stages of 48 KiB filled by
-// global_load_lds with a counted s_waitcnt vmcnt(6): while stage kt is consumed, stages kt+1
-// and kt+2 are in flight (96 KiB per CU), which is what the ~1.5 us loaded L2/HBM latency
-// needs (the 2-stage loop is latency-bound: one vmcnt(0) + barrier per K-step).
-// One raw s_barrier per K-step.  LDS: 3 x (A0 | A1 | B) x 16 KiB = 144 KiB, reused as the
-// fp32 epilogue image [256][128].
-// --------------------------------------------------------------------------------------
-constexpr int P3_BM = 256;
-constexpr int P3_THREADS = 512;
-constexpr int P3_STAGE = 3 * OP16_BYTES;          // 48 KiB
-constexpr int P3_LDS = 3 * P3_STAGE;              // 147456
-
-template <bool AK, bool BKM, typename OutT>
-__global__ __launch_bounds__(P3_THREADS) void gemm_bf16_p3_kernel(KParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;                  // 4 x 2 waves
-
-  int tile, split;
-  tile_and_split(p, tile, split);
-  const long m0 = (long)(tile / p.tiles_n) * P3_BM;
-  const long n0 = (long)(tile % p.tiles_n) * BN;
-  const int z = blockIdx.z;
-  const long zo = z / p.batch_inner, zi = z % p.batch_inner;
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
-  const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
-  OutT* C = reinterpret_cast<OutT*>(p.C) + zo * p.sCo + zi * p.sCi;
-
-  const long kbeg = (long)split * p.k_per_split;
-  const long kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = p.dbg == 2 ? 0 : (int)((kend - kbeg) / BK16);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0) && (wc == 0);
-  f32x4 racc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) racc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
-
-  // this wave's 6 pieces per stage: 4 of A (32 pieces = 2 sub-images x 16), 2 of B (16 pieces)
-  const bf16_t* sa[4];
-  const bf16_t* sb[2];
-  int da[4], db[2];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int qa = wave * 4 + j, sub = qa >> 4, q = qa & 15;
-    sa[j] = glds_src<AK>(A, p.lda, m0 + sub * 128, p.M, kbeg, q, lane);
-    da[j] = sub * OP16_BYTES + q * 1024;
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = wave * 2 + j;
-    sb[j] = glds_src<BKM>(Bm, p.ldb, n0, p.N, kbeg, q, lane);
-    db[j] = 2 * OP16_BYTES + q * 1024;
-  }
-  auto issue = [&](int buf) {
-    char* st = smem + buf * P3_STAGE;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + da[j]), 16, 0, 0);
-      sa[j] += AK ? BK16 : BK16 * p.lda;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)sb[j], (lptr_t)(st + db[j]), 16, 0, 0);
-      sb[j] += BKM ? BK16 : BK16 * p.ldb;
-    }
-  };
-
-  if (nk > 0) issue(0);
-  if (nk > 1) issue(1);
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);          // (kt+2) % 3
-    const char* st = smem + cur * P3_STAGE;
-    const char* la = st + (wr >> 1) * OP16_BYTES;
-    const char* lb = st + 2 * OP16_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = load_frag16<AK>(la, (wr & 1) * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = load_frag16<BKM>(lb, wc * 64 + j * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      if (do_rowsum) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) racc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], racc[i], 0, 0, 0);
-      }
-    }
-    cur = cur == 2 ? 0 : cur + 1;
-  }
-  __syncthreads();
-  if (p.dbg == 1) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (s == 12345.678f) C[0] = from_f32<OutT>(s);
-    return;
-  }
-
-  float* epi = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = wr * 64 + i * 16 + (lane & 15);
-      const int n = wc * 64 + j * 16 + 4 * (lane >> 4);
-      *reinterpret_cast<f32x4*>(epi + epi_off(m, n)) = acc[i][j];
-    }
-  __syncthreads();
-  run_epilogue<bf16_t, OutT, P3_BM, P3_THREADS>(p, epi, m0, n0, C, split == 0, tid);
-
-  if (do_rowsum && lane < 16) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long m = m0 + wr * 64 + i * 16 + lane;
-      if (m < p.M) atomicAdd(p.a_rowsum + m, racc[i][0]);
-    }
-  }
-}
-
-template <typename Kn>
-int launch_p3(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P3_LDS);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kernel, grid, dim3(P3_THREADS), P3_LDS, st, kp);
-  FAVIT_CHECK_LAUNCH();
-  return FAVIT_OK;
-}
-
-// --------------------------------------------------------------------------------------
 // bf16 kernel "p4": 256x128 tile, 8 waves, BK = 32, three 24-KiB LDS stages (72 KiB -> TWO
 // workgroups per CU) and an epilogue that runs straight from the accumulator registers (no
 // LDS staging, no barrier): one workgroup's prologue / epilogue / store drain overlaps the
@@ -699,8 +554,8 @@ int launch_p3(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
 // lone workgroup cost as much as the whole main loop.
 //   k-major image : [rows][32 k]  (64-B rows), 16-B chunk c stored at c ^ ((-(row>>2)) & 3)
 //   mn-major image: [32 k][128 i] (256-B rows), same 32-B XOR swizzle as the BK=64 image
-// Lane l of an accumulator tile holds C[m = l&15][n = 4*(l>>4) .. +3]: 8-B (bf16) / 16-B (f32)
-// stores, 16 rows per wave-instruction; the four n-tiles of a wave complete 128-B lines.
+// (Storing straight from the MFMA layout -- 32-B pieces per row -- measured 1.7 TB/s on the
+// two-output fc1 epilogue; the wave-private LDS transpose below writes full 128/256-B row segments.)
 // --------------------------------------------------------------------------------------
 constexpr int P4_BM = 256;
 constexpr int P4_BK = 32;
@@ -744,83 +599,6 @@ __device__ __forceinline__ bf16x8 load_frag32(const char* lds, int r0, int lane)
   }
 }
 
-template <typename InT, typename OutT>
-__device__ __forceinline__ void direct_epilogue(const KParams& p, const f32x4 (&acc)[4][4], OutT* C, long mbase,
-                                                long nbase, int lane) {
-  const int lm = lane & 15, ln = 4 * (lane >> 4);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const long n = nbase + j * 16 + ln;
-    if (n >= p.N) continue;
-    const bool nvec = p.c_vec && (n + 4 <= p.N);
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-      if (nvec) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        bv[0] = b.x; bv[1] = b.y; bv[2] = b.z; bv[3] = b.w;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long m = mbase + i * 16 + lm;
-      if (m >= p.M) continue;
-      float a[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) a[r] = fmaf(acc[i][j][r], p.alpha, bv[r]);
-      if (nvec) {
-        if (p.aux_out) {
-          OutT* ao = reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n;
-          if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float4*>(ao) = make_float4(a[0], a[1], a[2], a[3]);
-          else { bf16x4 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]}; *reinterpret_cast<bf16x4*>(ao) = o; }
-        }
-        if (p.act == FAVIT_ACT_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a[r] = epi_gelu<InT>(a[r]);
-        } else if (p.act == FAVIT_ACT_DGELU) {
-          const InT* ai = reinterpret_cast<const InT*>(p.aux_in) + m * p.ld_aux_in + n;
-          float x[4];
-          if constexpr (sizeof(InT) == 4) { const float4 t = *reinterpret_cast<const float4*>(ai); x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w; }
-          else { const bf16x4 t = *reinterpret_cast<const bf16x4*>(ai); x[0] = (float)t[0]; x[1] = (float)t[1]; x[2] = (float)t[2]; x[3] = (float)t[3]; }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a[r] *= epi_dgelu<InT>(x[r]);
-        }
-        if (p.drop_thresh) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            a[r] = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n + r), p.drop_thresh) ? a[r] * p.drop_scale : 0.f;
-        }
-        if (p.residual) {
-          const float4 rr = *reinterpret_cast<const float4*>(p.residual + m * p.ld_res + n);
-          a[0] += rr.x; a[1] += rr.y; a[2] += rr.z; a[3] += rr.w;
-        }
-        OutT* co = C + m * p.ldc + n;
-        if constexpr (sizeof(OutT) == 4) *reinterpret_cast<float4*>(co) = make_float4(a[0], a[1], a[2], a[3]);
-        else { bf16x4 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]}; *reinterpret_cast<bf16x4*>(co) = o; }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r >= p.N) continue;
-          float v = a[r];
-          if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n + r] = from_f32<OutT>(v);
-          if (p.act == FAVIT_ACT_GELU) v = epi_gelu<InT>(v);
-          else if (p.act == FAVIT_ACT_DGELU)
-            v *= epi_dgelu<InT>(to_f32(reinterpret_cast<const InT*>(p.aux_in)[m * p.ld_aux_in + n + r]));
-          if (p.drop_thresh) v = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n + r), p.drop_thresh) ? v * p.drop_scale : 0.f;
-          if (p.residual) v += p.residual[m * p.ld_res + n + r];
-          C[m * p.ldc + n + r] = from_f32<OutT>(v);
-        }
-      }
-    }
-  }
-}
-
-// Epilogue through a WAVE-PRIVATE LDS transpose (no workgroup barrier): the wave's 64x64
-// accumulator block goes through LDS in two 32-row halves so that every global access is a full
-// row segment (64 cols = 128 B bf16 / 256 B f32 contiguous per row, 16 B per lane) instead of the
-// 32-B pieces of the raw MFMA layout (which measured 1.7 TB/s on the two-output fc1 epilogue).
 // 16-byte output store with a cache policy: 0 plain, 1 non-temporal (nt), 2 write-through (sc1).
 // GEMM outputs are written once and not re-read by this kernel; keeping them out of the XCD L2
 // protects the A/B operand lines that co-resident workgroups still share.
@@ -1079,10 +857,6 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
 #pragma unroll
       for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (s == 12345.678f) C[0] = from_f32<OutT>(s);
-    return;
-  }
-  if (p.dbg == 3) {
-    direct_epilogue<bf16_t, OutT>(p, acc, C, m0 + wr * 64, n0 + wc * 64, lane);
     return;
   }
   __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
@@ -1458,25 +1232,6 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
         case 2: return launch_p4(gemm_bf16_p4_kernel<true, false, float>, kp, grid4, st);
         case 1: return launch_p4(gemm_bf16_p4_kernel<false, true, float>, kp, grid4, st);
         default: return launch_p4(gemm_bf16_p4_kernel<false, false, float>, kp, grid4, st);
-      }
-    }
-  }
-  if (glds_ok && !force128 && g->M >= 1024 && (long)((g->M + 255) / 256) * tiles_n * splits * batch >= 128) {
-    KParams k3 = kp;
-    dim3 grid3((unsigned)(((g->M + 255) / 256) * tiles_n), (unsigned)splits, (unsigned)batch);
-    if (g->out_dtype == FAVIT_BF16) {
-      switch (layout) {
-        case 3: return launch_p3(gemm_bf16_p3_kernel<true, true, bf16_t>, k3, grid3, st);
-        case 2: return launch_p3(gemm_bf16_p3_kernel<true, false, bf16_t>, k3, grid3, st);
-        case 1: return launch_p3(gemm_bf16_p3_kernel<false, true, bf16_t>, k3, grid3, st);
-        default: return launch_p3(gemm_bf16_p3_kernel<false, false, bf16_t>, k3, grid3, st);
-      }
-    } else {
-      switch (layout) {
-        case 3: return launch_p3(gemm_bf16_p3_kernel<true, true, float>, k3, grid3, st);
-        case 2: return launch_p3(gemm_bf16_p3_kernel<true, false, float>, k3, grid3, st);
-        case 1: return launch_p3(gemm_bf16_p3_kernel<false, true, float>, k3, grid3, st);
-        default: return launch_p3(gemm_bf16_p3_kernel<false, false, float>, k3, grid3, st);
       }
     }
   }
