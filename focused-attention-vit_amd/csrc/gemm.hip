@@ -63,7 +63,6 @@ struct KParams {
   int ntiles;          // output tiles per (split, batch)
   int xcd_split;       // 1: 1-D grid of ntiles*nsplit blocks, all tiles of a split on one XCD
   int store_policy;    // cache policy of the epilogue's output stores (store16_policy)
-  int stagger_ticks;   // 100 MHz ticks the second resident set of p4 workgroups waits at start
   int dbg;     // experiments only (FAVIT_GEMM_DBG): 1 = skip epilogue, 2 = skip main loop
 };
 
@@ -556,6 +555,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_glds_kernel(KParams p) {
 //   mn-major image: [32 k][128 i] (256-B rows), same 32-B XOR swizzle as the BK=64 image
 // (Storing straight from the MFMA layout -- 32-B pieces per row -- measured 1.7 TB/s on the
 // two-output fc1 epilogue; the wave-private LDS transpose below writes full 128/256-B row segments.)
+// Measured alternatives (tools/dma_probe.py, tools/overlap_probe.py, round 1):
+//  * the operand stream of this tile alone (no MFMA) moves 13.9 TB/s L2->LDS; with BK = 64 (whole
+//    128-B lines per row and step) and three 48-KiB stages it moves 19.3 TB/s, but 144 KiB of LDS
+//    leave one workgroup (2 waves/SIMD) per CU, whose LDS-read + MFMA phase then takes 1.0 us per
+//    48-KiB step -- a persistent BK = 64 variant ran the main loop at 850 TF vs 950 TF here;
+//  * an HBM store or load stream running beside the main loop adds its full time (concurrent
+//    fill + main loop = sum of both): epilogue traffic and the L2-bound loop share the L2/fabric
+//    path, so a phase stagger between the two co-resident workgroups buys nothing (measured).
 // --------------------------------------------------------------------------------------
 constexpr int P4_BM = 256;
 constexpr int P4_BK = 32;
@@ -621,16 +628,17 @@ __device__ __forceinline__ void store16_policy(void* ptr, uint4 v, int policy) {
 constexpr int WEPI_LD = 68;                         // padded fp32 row
 constexpr int WEPI_BYTES = 32 * WEPI_LD * 4;        // 8704 B per wave
 
-template <typename InT, typename OutT, int half, int NJ = 4, int CB = 0>
-__device__ __forceinline__ void wave_epilogue_half(const KParams& p, const f32x4 (&acc)[4][NJ], OutT* C, long mbase,
+// rows [16*Q, 16*(Q+NI)) of the wave's 64x64 accumulator tile (NI = 1 or 2 groups of 16 rows)
+template <typename InT, typename OutT, int Q, int NI, int NJ = 4, int CB = 0>
+__device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4 (&acc)[4][NJ], OutT* C, long mbase,
                                               long nbase, int lane, float* wl, bool first_split) {
   const bool fast = p.c_vec && (nbase + 64 <= p.N);
   {
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+    for (int ii = 0; ii < NI; ++ii)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4*>(wl + (ii * 16 + (lane & 15)) * WEPI_LD + j * 16 + 4 * (lane >> 4)) = acc[half * 2 + ii][CB * 4 + j];
+        *reinterpret_cast<f32x4*>(wl + (ii * 16 + (lane & 15)) * WEPI_LD + j * 16 + 4 * (lane >> 4)) = acc[Q + ii][CB * 4 + j];
     // (same wave wrote and reads: the compiler's lgkmcnt wait orders them; no barrier needed)
     bool done = false;
     if constexpr (sizeof(OutT) == 4) {
@@ -638,8 +646,8 @@ __device__ __forceinline__ void wave_epilogue_half(const KParams& p, const f32x4
         // split-K / accumulate: fp32 atomics, one 256-B contiguous row segment per wave-instruction
         const long n = nbase + lane;
         const float bv = (first_split && p.bias && n < p.N) ? p.bias[n] : 0.f;
-        for (int row = 0; row < 32; ++row) {
-          const long m = mbase + half * 32 + row;
+        for (int row = 0; row < 16 * NI; ++row) {
+          const long m = mbase + Q * 16 + row;
           if (m < p.M && n < p.N) {
             float v = fmaf(wl[row * WEPI_LD + lane], p.alpha, bv);
             if (first_split && p.residual) v += p.residual[m * p.ld_res + n];
@@ -655,9 +663,9 @@ __device__ __forceinline__ void wave_epilogue_half(const KParams& p, const f32x4
     constexpr int RPI = 64 / LPR;                           // rows per iteration
     const int lr = lane / LPR, lc = (lane % LPR) * CPL;
 #pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
+    for (int it = 0; it < 16 * NI / RPI; ++it) {
       const int row = it * RPI + lr;
-      const long m = mbase + half * 32 + row, n = nbase + lc;
+      const long m = mbase + Q * 16 + row, n = nbase + lc;
       if (m >= p.M) continue;
       float a[CPL];
 #pragma unroll
@@ -744,8 +752,8 @@ __device__ __forceinline__ void wave_epilogue_half(const KParams& p, const f32x4
 template <typename InT, typename OutT>
 __device__ __forceinline__ void wave_epilogue(const KParams& p, const f32x4 (&acc)[4][4], OutT* C, long mbase,
                                               long nbase, int lane, float* wl, bool first_split) {
-  wave_epilogue_half<InT, OutT, 0>(p, acc, C, mbase, nbase, lane, wl, first_split);
-  wave_epilogue_half<InT, OutT, 1>(p, acc, C, mbase, nbase, lane, wl, first_split);
+  wave_epilogue_rows<InT, OutT, 0, 2>(p, acc, C, mbase, nbase, lane, wl, first_split);
+  wave_epilogue_rows<InT, OutT, 2, 2>(p, acc, C, mbase, nbase, lane, wl, first_split);
 }
 
 template <bool AK, bool BKM, typename OutT>
@@ -807,14 +815,6 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
     sb += BKM ? P4_BK : P4_BK * p.ldb;
   };
 
-  // Phase stagger: the two workgroups that share a CU would otherwise run in lockstep (main loop
-  // together, epilogue together) and never overlap MFMA with the store-heavy epilogue.  The second
-  // resident set (blocks 256..511 of the launch) starts half a tile late; later blocks inherit the
-  // phase of the slot they replace.
-  if (p.stagger_ticks > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(8);
-  }
   if (nk > 0) issue(0);
   if (nk > 1) issue(1);
   int cur = 0;
@@ -894,10 +894,15 @@ __global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_grouped_tn_kernel(
 
 template <typename Kn>
 int launch_p4(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS);
-    attr_set = true;
+  // one attribute call per distinct kernel (all instantiations share this function's type)
+  static const void* seen[32];
+  static int nseen = 0;
+  const void* kptr = reinterpret_cast<const void*>(kernel);
+  bool known = false;
+  for (int i = 0; i < nseen; ++i) known = known || seen[i] == kptr;
+  if (!known) {
+    (void)hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS);
+    if (nseen < 32) seen[nseen++] = kptr;
   }
   hipLaunchKernelGGL(kernel, grid, dim3(P4_THREADS), P4_LDS, st, kp);
   FAVIT_CHECK_LAUNCH();
@@ -1170,7 +1175,6 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.xcd_split = 0;
   kp.alpha = g->alpha;
   { const char* e = getenv("FAVIT_GEMM_DBG"); kp.dbg = e ? atoi(e) : 0; }
-  { const char* e = getenv("FAVIT_GEMM_STAGGER"); kp.stagger_ticks = e ? atoi(e) : 0; }
   // epilogue outputs / residual / aux reads are touched once: non-temporal keeps them from evicting
   // the operand panels the co-resident workgroups share in L2 (fc2: 140 -> 114 us)
   { const char* e = getenv("FAVIT_GEMM_STORE"); kp.store_policy = e ? atoi(e) : 1; }
@@ -1315,7 +1319,7 @@ extern "C" int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void
     kp.xcd_split = 1;
     kp.alpha = 1.0f;
     kp.drop_thresh = 0; kp.drop_scale = 1.0f; kp.drop_seed = 0;
-    kp.store_policy = 0; kp.stagger_ticks = 0; kp.dbg = 0;
+    kp.store_policy = 0; kp.dbg = 0;
     gp.tile_off[i] = off;
     off += kp.ntiles;
   }

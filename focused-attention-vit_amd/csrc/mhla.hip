@@ -222,7 +222,7 @@ struct AttnArgs {
   void* out;      // fwd: o ; bwd: dqkv
   const uint8_t* mask;
   int B, L, H, hd, W;
-  int rb;              // backward: key/query rows per workgroup (32 - 2h keeps phase 1 to one pass)
+  int rb;              // backward: key rows per workgroup (attn_entry sizes it to the LDS regions)
   int dbg;             // experiments only (FAVIT_MHLA_DBG)
   float inv_sqrt_hd;   // unused (true division is applied), kept for clarity
   uint32_t thresh;
@@ -264,7 +264,6 @@ __device__ __forceinline__ void row_softmax(const Slice<T, DPL>& q, const char* 
 }
 
 constexpr int FWD_QPB = 64;   // query rows per workgroup (forward)
-constexpr int BWD_RB = 32;    // key/query rows per workgroup (backward)
 
 template <typename T, int DPL, int WMAX>
 __global__ __launch_bounds__(256) void mhla_fwd_kernel(AttnArgs a) {
@@ -431,8 +430,8 @@ __global__ __launch_bounds__(256) void mhla_bwd_kernel(AttnArgs a) {
   __syncthreads();
 
   // ---- phase 2: per key row j: gather dK~, dV~ from the rows that reference it ----
-  {
-    const int j = r0 + qs;
+  for (int jb = r0; jb < r1; jb += 32) {
+    const int j = jb + qs;
     const bool valid = j < r1;
     float dk[DPL], dv[DPL];
 #pragma unroll
@@ -1086,7 +1085,18 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
   AttnArgs a;
   a.qkv = qkv; a.dout = dout; a.out = out; a.mask = mask;
   a.B = B; a.L = L; a.H = H; a.hd = hd; a.W = W;
-  a.rb = BWD_RB - 2 * (W / 2);
+  {
+    // backward row block: as many key rows as the fixed LDS regions allow (64 query / dO rows incl.
+    // the wrap rows, 80 K~/V~ rows incl. halo and edges), then balanced over the blocks of L
+    const int h = W / 2;
+    int rb_max = 64 - 3 * h - 1;
+    if (80 - 8 * h - 2 < rb_max) rb_max = 80 - 8 * h - 2;
+    if (rb_max < 1) return FAVIT_ERR_UNSUPPORTED;
+    const int nblk = (L + rb_max - 1) / rb_max;
+    a.rb = (L + nblk - 1) / nblk;
+    const char* e = getenv("FAVIT_MHLA_RB");
+    if (e && atoi(e) > 0 && atoi(e) <= rb_max) a.rb = atoi(e);
+  }
   { const char* e = getenv("FAVIT_MHLA_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.inv_sqrt_hd = 0.f;
   a.thresh = dropout_threshold(p);

@@ -1,0 +1,109 @@
+// Probe kernels for tools/overlap_probe.py (not part of libfavit).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <int POLICY>
+__global__ void fill_kernel(u32x4* dst, long n16, int wgs_limit) {
+  const u32x4 v = {1u, 2u, 3u, 4u};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+    if (POLICY == 1) __builtin_nontemporal_store(v, dst + i);
+    else dst[i] = v;
+  }
+}
+
+__global__ void read_kernel(const u32x4* src, long n16, unsigned* out) {
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+    const u32x4 t = __builtin_nontemporal_load(src + i);
+    acc += t;
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 0x12345u) out[0] = 1;
+}
+
+extern "C" int probe_fill(void* dst, long bytes, int policy, int blocks, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (policy == 1) hipLaunchKernelGGL(fill_kernel<1>, dim3(blocks), dim3(256), 0, st, (u32x4*)dst, bytes / 16, 0);
+  else hipLaunchKernelGGL(fill_kernel<0>, dim3(blocks), dim3(256), 0, st, (u32x4*)dst, bytes / 16, 0);
+  return 0;
+}
+extern "C" int probe_read(const void* src, long bytes, void* out, int blocks, void* stream) {
+  hipLaunchKernelGGL(read_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, bytes / 16, (unsigned*)out);
+  return 0;
+}
+
+// ---- L2 -> LDS DMA probe: the operand traffic of a 256x128 GEMM tile without the math ----
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int CHUNK, int NSTAGE>
+__global__ __launch_bounds__(512) void dma_probe(const char* A, const char* W, long lda, long ldw, long M, int tiles_n,
+                                                 int ksteps, unsigned* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = 384, STAGE = ROWS * CHUNK, PIECES = STAGE / 1024, PPW = PIECES / 8;
+  constexpr int LPR = CHUNK / 16, RPP = 64 / LPR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long m0 = (long)(tile / tiles_n) * 256, n0 = (long)(tile % tiles_n) * 128;
+  const char* src[PPW];
+  int dst[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int q = wave * PPW + j, row = q * RPP + lane / LPR, c = lane % LPR;
+    long m = m0 + row; m = m < M ? m : M - 1;
+    src[j] = row < 256 ? A + m * lda + c * 16 : W + (n0 + row - 256) * ldw + c * 16;
+    dst[j] = q * 1024;
+  }
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)src[j], (lptr_t)(smem + buf * STAGE + dst[j]), 16, 0, 0);
+      src[j] += CHUNK;
+    }
+  };
+  unsigned acc = 0;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s) if (s < ksteps) issue(s);
+  int cur = 0;
+  for (int kt = 0; kt < ksteps; ++kt) {
+    if (kt + NSTAGE - 1 <= ksteps) {
+      if (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (PPW * (NSTAGE - 2) == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (PPW * (NSTAGE - 2) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (PPW * (NSTAGE - 2) == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTAGE - 1 < ksteps) issue((cur + NSTAGE - 1) % NSTAGE);
+    acc += *reinterpret_cast<const unsigned*>(smem + cur * STAGE + tid * 16);
+    cur = (cur + 1) % NSTAGE;
+  }
+  if (acc == 0x13572468u) sink[0] = acc;
+}
+
+extern "C" int probe_dma(const void* A, const void* W, long lda, long ldw, long M, int tiles_n, int ntiles, int ksteps,
+                         int chunk, int nstage, int lds_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  static unsigned* sink = nullptr;
+  if (!sink) hipMalloc(&sink, 64);
+#define LAUNCH(C, S)                                                                                          \
+  do {                                                                                                        \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(dma_probe<C, S>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        lds_bytes);                                                                           \
+    hipLaunchKernelGGL((dma_probe<C, S>), dim3(ntiles), dim3(512), lds_bytes, st, (const char*)A, (const char*)W, \
+                       lda, ldw, M, tiles_n, ksteps, sink);                                                   \
+  } while (0)
+  if (chunk == 64 && nstage == 3) LAUNCH(64, 3);
+  else if (chunk == 64 && nstage == 4) LAUNCH(64, 4);
+  else if (chunk == 128 && nstage == 2) LAUNCH(128, 2);
+  else if (chunk == 128 && nstage == 3) LAUNCH(128, 3);
+  else return -1;
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
