@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
+HBM_PEAK_GBPS = 8000.0
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MFMA_PEAK_TFLOPS = 157.3
 
@@ -203,6 +204,12 @@ def main():
                                "frac": round(ach / peak, 4), "traffic": traffic,
                                "kernel": f"gemm_{dom}", "launches": n, "avg_launch_us": round(1e6 * sec / n, 2),
                                "avg_flops_per_launch": round(fl / n, 1)}
+            if traffic:
+                # the same launches seen from the memory side (these K<=1536 GEMMs sit near the
+                # 312 flop/B machine balance): measured HBM bytes / launch time vs the 8 TB/s peak
+                gbps = traffic / (sec / n) / 1e9
+                out["roofline"]["hbm_view"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                               "frac": round(gbps / HBM_PEAK_GBPS, 4)}
             tot = sum(v[0] for v in fam.values())
             out["gemm_families"] = {k: {"ms_per_step": round(1e3 * v[0] / traced_steps, 3),
                                         "tflops": round(v[1] / v[0] / 1e12, 1), "launches_per_step": v[2] // traced_steps}
