@@ -135,7 +135,6 @@ def bump_weight_epoch() -> None:
     _STATE["epoch"] += 1
 
 
-_WCACHE = {}
 # parameter storage -> (fp32 flat buffer, bf16 mirror) kept fresh by the fused optimizer (train.FusedAdamW)
 _LP_MIRRORS = []
 
@@ -152,9 +151,20 @@ def clear_lp_mirrors() -> None:
     _LP_MIRRORS.clear()
 
 
+def invalidate_weight_cache() -> None:
+    """Drop every cached compute-dtype copy of a parameter.  Needed only after editing parameters
+    through ``.data`` (``p.data.copy_(...)``), which autograd's version counter cannot see, once a
+    bf16-mode forward has already run; ``load_state_dict``, ``nn.init.*`` and optimizer steps are
+    detected automatically."""
+    _STATE["epoch"] += 1
+
+
 def wcast(w: torch.Tensor) -> torch.Tensor:
-    """Parameter in the compute dtype (cached per (storage, version, epoch))."""
+    """Parameter in the compute dtype.  The copy is cached ON the tensor object that was passed in
+    (so it dies with the parameter: another model whose weights later reuse the same address can
+    never see it) and is tagged with (address, version counter, weight epoch, dtype)."""
     cdt = _STATE["cdt"]
+    src = w
     w = w.detach()
     if w.dtype == cdt and w.is_contiguous():
         return w
@@ -169,13 +179,15 @@ def wcast(w: torch.Tensor) -> torch.Tensor:
             if base <= ptr < base + 4 * fp.numel():
                 off = (ptr - base) // 4
                 return lp[off:off + w.numel()].view(w.shape)
-    key = (w.data_ptr(), tuple(w.shape))
-    tag = (w._version, _STATE["epoch"], cdt)
-    hit = _WCACHE.get(key)
+    tag = (w.data_ptr(), tuple(w.shape), w._version, _STATE["epoch"], cdt)
+    hit = getattr(src, "_favit_cast", None)
     if hit is not None and hit[0] == tag:
         return hit[1]
     c = K.cast(w, cdt)
-    _WCACHE[key] = (tag, c)
+    try:
+        src._favit_cast = (tag, c)
+    except AttributeError:                    # pragma: no cover  (objects without a __dict__)
+        pass
     return c
 
 

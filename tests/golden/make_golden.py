@@ -297,6 +297,92 @@ def gen_models():
     save("models.npz", out)
 
 
+def _gnorms(out, key, m):
+    for k, p in m.named_parameters():
+        out[f"{key}/gnorm/{k}"] = np.float32(0.0 if p.grad is None else p.grad.norm().item())
+
+
+def _maps_with_R(img, P, n_regions, want_R, count, seed0):
+    """`count` seeded Voronoi label maps whose reference patch->superpixel dict has `want_R` keys."""
+    mapper = rsppp.PatchToSuperpixelMapper(P)
+    maps, seed = [], seed0
+    while len(maps) < count:
+        sm = voronoi_labels(img, n_regions, seed=seed)
+        if len(mapper.map_patches(torch.from_numpy(sm), img)) == want_R:
+            maps.append((seed, sm))
+        seed += 1
+    return maps
+
+
+def gen_configs():
+    """Whole-model fixtures at BASELINE.json configs[2..4] (weights and inputs are regenerated from the
+    seed by the tests: only seeds, label maps, logits, loss and gradient norms are stored)."""
+    out = {}
+    ce = torch.nn.CrossEntropyLoss()
+    # cfg3: SPPP+MHLA Small, 224/p16, 16 superpixels (R = 16 -> 17 tokens), mean pooling
+    maps16 = _maps_with_R(224, 16, 16, 16, 4, 100)
+    out["cfg3/map_seeds"] = np.asarray([s for s, _ in maps16], dtype=np.int64)
+    segs = torch.from_numpy(np.stack([m for _, m in maps16]))
+    out["cfg3/segmaps"] = segs.numpy().astype(np.uint8)
+    torch.manual_seed(1234)
+    m = rsm.SPPPViTMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12, num_heads=6,
+                        num_superpixels=16, pooling_type="mean", window_size=7, use_mhla=True)
+    m.eval()
+    m.segmentation.segment = lambda x, _s=segs: _s
+    x = torch.randn(4, 3, 224, 224)
+    y = torch.randint(0, 1000, (4,))
+    logits = m(x)
+    loss = ce(logits, y)
+    loss.backward()
+    out["cfg3/x_sum"], out["cfg3/y"] = np.float64(x.double().sum().item()), y.numpy()
+    out["cfg3/logits"], out["cfg3/loss"] = np32(logits), np32(loss)
+    out["cfg3/param_sum"] = np.float64(sum(p.double().sum().item() for p in m.parameters()))
+    _gnorms(out, "cfg3", m)
+    # cfg5: the fine-tune setup of experiments/sppp_mhla_pretrained.py:236-237 (identity latent_proj,
+    # zero bias) with "mixed superpixel counts": one bucket with R = 16 and one with R = 15
+    maps15 = _maps_with_R(224, 16, 15, 15, 2, 200)
+    out["cfg5/map_seeds15"] = np.asarray([s for s, _ in maps15], dtype=np.int64)
+    segs15 = torch.from_numpy(np.stack([m_ for _, m_ in maps15]))
+    out["cfg5/segmaps15"] = segs15.numpy().astype(np.uint8)
+    torch.manual_seed(4321)
+    m = rsm.SPPPViTMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12, num_heads=6,
+                        num_superpixels=16, pooling_type="mean", window_size=7, use_mhla=True)
+    for blk in m.blocks:
+        torch.nn.init.eye_(blk.attn.latent_proj.weight)
+        torch.nn.init.zeros_(blk.attn.latent_proj.bias)
+    m.eval()
+    x16 = torch.randn(2, 3, 224, 224)
+    x15 = torch.randn(2, 3, 224, 224)
+    y16 = torch.randint(0, 1000, (2,))
+    m.segmentation.segment = lambda x, _s=segs[:2]: _s
+    lg16 = m(x16)
+    loss = ce(lg16, y16)
+    loss.backward()
+    out["cfg5/x16_sum"], out["cfg5/x15_sum"] = np.float64(x16.double().sum().item()), np.float64(x15.double().sum().item())
+    out["cfg5/y16"] = y16.numpy()
+    out["cfg5/logits16"], out["cfg5/loss16"] = np32(lg16), np32(loss)
+    _gnorms(out, "cfg5", m)
+    m.segmentation.segment = lambda x, _s=segs15: _s
+    with torch.no_grad():
+        out["cfg5/logits15"] = np32(m(x15))
+    # cfg4: ViT-MHLA-Base 384/p16 (577 tokens), one image
+    torch.manual_seed(1234)
+    m = rvm.VisionTransformerMHLA(img_size=384, patch_size=16, num_classes=1000, embed_dim=768, depth=12,
+                                  num_heads=12, window_size=7, use_mhla=True)
+    m.eval()
+    x = torch.randn(1, 3, 384, 384)
+    y = torch.randint(0, 1000, (1,))
+    logits = m(x)
+    loss = ce(logits, y)
+    loss.backward()
+    out["cfg4/x_sum"], out["cfg4/y"] = np.float64(x.double().sum().item()), y.numpy()
+    out["cfg4/logits"], out["cfg4/loss"] = np32(logits), np32(loss)
+    out["cfg4/param_sum"] = np.float64(sum(p.double().sum().item() for p in m.parameters()))
+    out["cfg4/n_params"] = np.int64(m.get_num_parameters())
+    _gnorms(out, "cfg4", m)
+    save("configs.npz", out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_windows()
@@ -305,3 +391,4 @@ if __name__ == "__main__":
     gen_cross()
     gen_sppp()
     gen_models()
+    gen_configs()

@@ -1,0 +1,154 @@
+"""Whole-model parity at BASELINE.json configs[2..4] (SPPP+MHLA Small; ViT-MHLA-Base 384/p16, 577
+tokens; the SPPP fine-tune setup with identity latent_proj and mixed superpixel counts).
+
+tests/golden/configs.npz holds what the REFERENCE produced for seeded weights / inputs (generated
+by tests/golden/make_golden.py::gen_configs); weights and inputs are regenerated here from the same
+seeds (the mirrors reproduce the reference's init RNG order, a24).  CPU tests pin the oracle at
+these sizes, GPU tests the HIP path."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from oracle import favit_oracle as O
+
+CF = load_golden("configs.npz")
+DEV = "cuda"
+
+
+def _sppp_small(favit, seed, identity_latent=False):
+    torch.manual_seed(seed)
+    m = favit.models.sppp_mhla.SPPPViTMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12,
+                                          num_heads=6, num_superpixels=16, pooling_type="mean", window_size=7,
+                                          use_mhla=True)
+    if identity_latent:      # experiments/sppp_mhla_pretrained.py:236-237
+        for blk in m.blocks:
+            torch.nn.init.eye_(blk.attn.latent_proj.weight)
+            torch.nn.init.zeros_(blk.attn.latent_proj.bias)
+    return m.eval()
+
+
+def _cfg3_inputs():
+    x = torch.randn(4, 3, 224, 224)
+    y = torch.randint(0, 1000, (4,))
+    assert abs(x.double().sum().item() - float(CF["cfg3/x_sum"])) < 1e-6
+    assert torch.equal(y, torch.from_numpy(CF["cfg3/y"]))
+    return x, y, CF["cfg3/segmaps"].astype(np.int64)
+
+
+def _cfg5_inputs():
+    x16 = torch.randn(2, 3, 224, 224)
+    x15 = torch.randn(2, 3, 224, 224)
+    y16 = torch.randint(0, 1000, (2,))
+    assert abs(x16.double().sum().item() - float(CF["cfg5/x16_sum"])) < 1e-6
+    assert abs(x15.double().sum().item() - float(CF["cfg5/x15_sum"])) < 1e-6
+    assert torch.equal(y16, torch.from_numpy(CF["cfg5/y16"]))
+    return x16, x15, y16, CF["cfg3/segmaps"][:2].astype(np.int64), CF["cfg5/segmaps15"].astype(np.int64)
+
+
+def _base384(favit):
+    torch.manual_seed(1234)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=384, patch_size=16, num_classes=1000, embed_dim=768,
+                                                    depth=12, num_heads=12, window_size=7, use_mhla=True)
+    x = torch.randn(1, 3, 384, 384)
+    y = torch.randint(0, 1000, (1,))
+    assert abs(x.double().sum().item() - float(CF["cfg4/x_sum"])) < 1e-6 and torch.equal(y, torch.from_numpy(CF["cfg4/y"]))
+    return m.eval(), x, y
+
+
+def _oracle_sd(m):
+    return {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+
+
+def _gn_worst(named_grads, key):
+    worst = 0.0
+    for k, g in named_grads:
+        r = float(CF[f"{key}/gnorm/{k}"])
+        gn = 0.0 if g is None else g.norm().item()
+        worst = max(worst, abs(gn - r) / max(r, 1e-10))
+    return worst
+
+
+# ------------------------------------------------------------------ CPU: the oracle at these sizes
+def test_oracle_cfg3_sppp_mhla_small(favit):
+    m = _sppp_small(favit, 1234)
+    assert abs(sum(p.double().sum().item() for p in m.parameters()) - float(CF["cfg3/param_sum"])) < 1e-6
+    x, y, segs = _cfg3_inputs()
+    sd = _oracle_sd(m)
+    logits = O.sppp_vit_mhla_forward(x, segs, sd, 16, 6, 7, True, S=16, kind="mean")
+    assert rel_l2(logits, CF["cfg3/logits"]) < 1e-4
+    loss = O.cross_entropy(logits, y)
+    assert abs(loss.item() - float(CF["cfg3/loss"])) < 1e-4 * abs(float(CF["cfg3/loss"]))
+    loss.backward()
+    names = [k for k, _ in m.named_parameters()]
+    assert _gn_worst(((k, sd[k].grad) for k in names), "cfg3") < 2e-3
+
+
+def test_oracle_cfg5_identity_latent_mixed_counts(favit):
+    m = _sppp_small(favit, 4321, identity_latent=True)
+    x16, x15, y16, segs16, segs15 = _cfg5_inputs()
+    sd = _oracle_sd(m)
+    lg16 = O.sppp_vit_mhla_forward(x16, segs16, sd, 16, 6, 7, True, S=16, kind="mean")
+    assert rel_l2(lg16, CF["cfg5/logits16"]) < 1e-4
+    with torch.no_grad():     # R = 15 = S - 1: the reference skips the CLS centroid prepend (sppp.py:271-274)
+        lg15 = O.sppp_vit_mhla_forward(x15, segs15, sd, 16, 6, 7, True, S=16, kind="mean")
+    assert rel_l2(lg15, CF["cfg5/logits15"]) < 1e-4
+
+
+def test_oracle_cfg4_vit_mhla_base_577_tokens(favit):
+    m, x, y = _base384(favit)
+    assert abs(sum(p.double().sum().item() for p in m.parameters()) - float(CF["cfg4/param_sum"])) < 1e-6
+    assert m.get_num_parameters() == int(CF["cfg4/n_params"])
+    with torch.no_grad():
+        logits = O.vit_mhla_forward(x, dict(m.state_dict()), 16, 12, 7, True)
+    assert rel_l2(logits, CF["cfg4/logits"]) < 1e-4
+
+
+# ------------------------------------------------------------------ GPU: the HIP path
+def _gpu_check(favit, m, logits, y, key, lkey, losskey, tl, tg):
+    assert rel_l2(logits.detach().cpu(), CF[lkey]) < tl, rel_l2(logits.detach().cpu(), CF[lkey])
+    loss = favit.train.cross_entropy(logits, y.to(DEV))
+    assert abs(loss.item() - float(CF[losskey])) < tl * abs(float(CF[losskey]))
+    loss.backward()
+    worst = _gn_worst(((k, p.grad) for k, p in m.named_parameters()), key)
+    assert worst < tg, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tl,tg", [("fp32", 1e-3, 2e-3), ("bf16", 2e-2, 5e-2)])
+def test_gpu_cfg3_sppp_mhla_small(favit, mode, tl, tg):
+    favit.set_compute_dtype(mode)
+    m = _sppp_small(favit, 1234)
+    x, y, segs = _cfg3_inputs()
+    m.to(DEV)
+    m.segmentation.set_label_maps(torch.from_numpy(segs).to(DEV))
+    _gpu_check(favit, m, m(x.to(DEV)), y, "cfg3", "cfg3/logits", "cfg3/loss", tl, tg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tl,tg", [("fp32", 1e-3, 2e-3), ("bf16", 2e-2, 5e-2)])
+def test_gpu_cfg5_identity_latent_mixed_counts(favit, mode, tl, tg):
+    favit.set_compute_dtype(mode)
+    m = _sppp_small(favit, 4321, identity_latent=True)
+    x16, x15, y16, segs16, segs15 = _cfg5_inputs()
+    m.to(DEV)
+    m.segmentation.set_label_maps(torch.from_numpy(segs15).to(DEV))      # bucket R = 15
+    with torch.no_grad():
+        lg15 = m(x15.to(DEV))
+    assert rel_l2(lg15.cpu(), CF["cfg5/logits15"]) < tl
+    m.segmentation.set_label_maps(torch.from_numpy(segs16).to(DEV))      # bucket R = 16
+    _gpu_check(favit, m, m(x16.to(DEV)), y16, "cfg5", "cfg5/logits16", "cfg5/loss16", tl, tg)
+    # a batch that mixes R = 15 and R = 16 cannot be stacked (reference: torch.stack error, sppp_mhla.py:300)
+    mixed = torch.from_numpy(np.stack([segs16[0], segs15[0]])).to(DEV)
+    m.segmentation.set_label_maps(mixed)
+    with pytest.raises(ValueError):
+        m(x16.to(DEV))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tl,tg", [("fp32", 1e-3, 2e-3), ("bf16", 2e-2, 5e-2)])
+def test_gpu_cfg4_vit_mhla_base_577_tokens(favit, mode, tl, tg):
+    favit.set_compute_dtype(mode)
+    m, x, y = _base384(favit)
+    m.to(DEV)
+    _gpu_check(favit, m, m(x.to(DEV)), y, "cfg4", "cfg4/logits", "cfg4/loss", tl, tg)

@@ -256,3 +256,36 @@ def test_direct_gradient_accumulation_matches_returned_grads(favit):
     w0 = m.head.weight.detach().clone()
     opt.step()
     assert not torch.equal(w0, m.head.weight)
+
+
+def test_bf16_weight_cache_does_not_leak_between_models(favit):
+    """Two models built one after the other usually get the SAME parameter addresses from the caching
+    allocator; the compute-dtype weight copies are cached per parameter object, so the second model must
+    never be served the first one's bf16 weights (regression: the cache used to be keyed by address)."""
+    import gc
+    x = torch.randn(2, 3, 32, 32, device=DEV)
+
+    def build(seed):
+        torch.manual_seed(seed)
+        return favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64,
+                                                           depth=2, num_heads=4, use_mhla=True).to(DEV).eval()
+    favit.set_compute_dtype("bf16")
+    a = build(1)
+    with torch.no_grad():
+        ya = a(x)
+    del a
+    gc.collect()
+    b = build(2)
+    with torch.no_grad():
+        yb = b(x)
+        favit.set_compute_dtype("fp32")
+        yb32 = b(x)
+    assert rel_l2(yb.float().cpu(), yb32.cpu()) < 2e-2
+    assert rel_l2(ya.float().cpu(), yb32.cpu()) > 0.1          # the two models really differ
+    # parameters edited through .data are invisible to the version counter: explicit invalidation
+    favit.set_compute_dtype("bf16")
+    with torch.no_grad():
+        b.head.weight.data.mul_(2.0)
+        favit.invalidate_weight_cache()
+        y2 = b(x)
+    assert rel_l2(y2.float().cpu(), 2 * (yb32.cpu() - b.head.bias.detach().cpu()) + b.head.bias.detach().cpu()) < 2e-2
