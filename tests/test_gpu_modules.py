@@ -289,3 +289,59 @@ def test_bf16_weight_cache_does_not_leak_between_models(favit):
         favit.invalidate_weight_cache()
         y2 = b(x)
     assert rel_l2(y2.float().cpu(), 2 * (yb32.cpu() - b.head.bias.detach().cpu()) + b.head.bias.detach().cpu()) < 2e-2
+
+
+def test_frozen_layers_flow_of_the_experiments(favit):
+    """experiments/mhla_pretrained.py:237-247 freezes everything except 'head' / 'latent_proj' by name:
+    frozen parameters get no gradient, trainable ones match the oracle."""
+    from oracle import favit_oracle as O
+    favit.set_compute_dtype("fp32")
+    torch.manual_seed(3)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2,
+                                                    num_heads=4, use_mhla=True).to(DEV).train()
+    for n, p in m.named_parameters():
+        p.requires_grad = ("head" in n) or ("latent_proj" in n)
+    x = torch.randn(3, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (3,), device=DEV)
+    loss = favit.train.cross_entropy(m(x), y)
+    loss.backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(("head" in k) or ("latent_proj" in k)) for k, v in m.state_dict().items()}
+    lo = O.cross_entropy(O.vit_mhla_forward(x.cpu(), sd, 4, 4, 7, True), y.cpu())
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-5
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert rel_l2(p.grad.cpu(), sd[n].grad) < 1e-4, n
+        else:
+            assert p.grad is None, n
+    # the fused optimizer only sees the trainable groups (5x lr on latent_proj, head lr)
+    groups = favit.train.param_groups(m, lr=1e-3, head_lr=1e-2)
+    assert sorted(len(g["params"]) for g in groups) == [2, 4]
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+def test_torch_optim_adamw_training_steps(favit, mode, tol):
+    """The reference's own loop (torch.optim.AdamW, experiments/mhla_pretrained.py:308-372) over three
+    steps: the cached compute-dtype weight copies must follow the optimizer's in-place updates."""
+    from oracle import favit_oracle as O
+    favit.set_compute_dtype(mode)
+    torch.manual_seed(5)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2,
+                                                    num_heads=4, use_mhla=True).to(DEV).train()
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    names = [k for k, _ in m.named_parameters()]
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2, weight_decay=0.05)
+    ropt = torch.optim.AdamW([sd[k] for k in names], lr=1e-2, weight_decay=0.05)
+    x = torch.randn(4, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (4,), device=DEV)
+    for step in range(3):
+        opt.zero_grad()
+        loss = torch.nn.CrossEntropyLoss()(m(x), y)
+        loss.backward()
+        opt.step()
+        ropt.zero_grad()
+        lo = O.cross_entropy(O.vit_mhla_forward(x.cpu(), sd, 4, 4, 7, True), y.cpu())
+        lo.backward()
+        ropt.step()
+        assert abs(loss.item() - lo.item()) < tol * max(1.0, abs(lo.item())), (step, loss.item(), lo.item())
+    assert lo.item() < 2.0        # three lr=1e-2 steps on one batch visibly reduce the loss (starts at ~2.3)
