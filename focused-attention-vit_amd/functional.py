@@ -265,6 +265,10 @@ def lin_bwd_w(dy, a, M, N, Kd, want_bias=True, wp=None, bp=None):
     """dw[N,K] = dy[M,N]^T @ a[M,K] (fp32, split-K over the tokens), db[N] = column sums of dy (fused).
     If the parameters wp / bp own usable .grad buffers the results are accumulated there and None
     is returned in their place."""
+    frozen_w = wp is not None and not wp.requires_grad
+    frozen_b = (not want_bias) or (bp is not None and not bp.requires_grad)
+    if frozen_w and frozen_b:          # frozen layer (experiments/mhla_pretrained.py:237-247): no weight-gradient GEMM
+        return None, None
     tw = _gt(wp)
     tb = _gt(bp) if want_bias else None
     dw = tw if tw is not None else torch.empty((N, Kd), dtype=torch.float32, device=dy.device)
