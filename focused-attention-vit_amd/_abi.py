@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfavit.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "favit.h")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
+E4M3, E5M2 = 0, 1
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 POOL = {"mean": 0, "max": 1, "attention": 2}
 
@@ -31,7 +32,8 @@ class GemmDesc(C.Structure):
         ("sAo", i64), ("sAi", i64), ("sBo", i64), ("sBi", i64), ("sCo", i64), ("sCi", i64),
         ("batch", i32), ("batch_inner", i32), ("a_kmajor", i32), ("b_kmajor", i32),
         ("in_dtype", i32), ("out_dtype", i32), ("act", i32), ("accumulate", i32), ("split_k", i32),
-        ("alpha", f32), ("dropout_p", f32), ("reserved_", i32), ("dropout_seed", u64),
+        ("alpha", f32), ("dropout_p", f32), ("fp8_fmt", i32), ("dropout_seed", u64),
+        ("scale_a", vp), ("scale_b", vp),
     ]
 
 
@@ -41,6 +43,8 @@ _SIGS = {
     "favit_gemm": ([C.POINTER(GemmDesc), vp], C.c_int),
     "favit_gemm_grouped_tn": ([C.POINTER(GemmDesc), i32, vp], C.c_int),
     "favit_cast": ([vp, C.c_int, vp, C.c_int, i64, vp], C.c_int),
+    "favit_fp8_amax": ([vp, C.c_int, i64, i64, i64, vp, vp], C.c_int),
+    "favit_fp8_quantize": ([vp, C.c_int, i64, i64, i64, vp, i64, vp, i64, C.c_int, vp, vp, vp, vp], C.c_int),
     "favit_layernorm_fwd": ([vp, i64, vp, vp, vp, C.c_int, vp, vp, i64, i32, f32, vp], C.c_int),
     "favit_layernorm_bwd": ([vp, C.c_int, vp, i64, vp, vp, vp, vp, vp, i64, vp, C.c_int, vp, vp, i32, vp, vp, i32,
                              i64, i32, vp], C.c_int),

@@ -1,0 +1,169 @@
+// FP8 operand preparation for the fp8 GEMM path (BASELINE.json configs[3]): per-tensor amax and
+// scaled conversion to OCP e4m3 / e5m2 (gfx950 encodings), with an optional transposed copy (the
+// weight-gradient and input-gradient GEMMs want their operands k-major, i.e. transposed) and an
+// optional column sum (bias gradient).  The reference has no counterpart: it is fp32 only.
+#include "common.h"
+
+namespace {
+
+constexpr float E4M3_MAX = 448.0f;
+constexpr float E5M2_MAX = 57344.0f;
+
+template <typename T>
+__global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ src, long rows, long cols, long ld,
+                                                   float* __restrict__ amax) {
+  float m = 0.f;
+  const long total = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols, c = i - r * cols;
+    m = fmaxf(m, fabsf(to_f32(src[r * ld + c])));
+  }
+  m = wave_max(m);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    // non-negative floats order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));
+  }
+}
+
+// two floats -> two fp8 bytes in the low half of the result (round to nearest even)
+template <int FMT>
+__device__ __forceinline__ unsigned cvt2(float a, float b) {
+  if (FMT == FAVIT_E4M3) return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+  return (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xffffu;
+}
+
+// One workgroup converts a 64 x 64 tile.  Thread t owns row (t >> 2), columns 16*(t & 3) .. +15:
+// 16 fp8 bytes = one 16-byte store of dst; the transposed copy goes through a padded LDS tile.
+template <typename T, int FMT>
+__global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ src, long rows, long cols, long ld,
+                                                       uint8_t* __restrict__ dst, long ld_dst,
+                                                       uint8_t* __restrict__ dst_t, long ld_t,
+                                                       const float* __restrict__ amax, float* __restrict__ scale_inv,
+                                                       float* __restrict__ colsum) {
+  __shared__ uint8_t tile[64][64 + 4];
+  __shared__ float csum[4][64];
+  constexpr float FMAX = FMT == FAVIT_E4M3 ? E4M3_MAX : E5M2_MAX;
+  const float am = amax[0];
+  const float scale = am > 0.f ? __fdiv_rn(FMAX, am) : 1.0f;           // IEEE division: reproducible scales
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_inv[0] = am > 0.f ? __fdiv_rn(am, FMAX) : 1.0f;
+  const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+  const int tr = threadIdx.x >> 2, tc = (threadIdx.x & 3) * 16;
+  const long r = r0 + tr;
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const long c = c0 + tc + j;
+    v[j] = (r < rows && c < cols) ? to_f32(src[r * ld + c]) : 0.f;
+  }
+  if (colsum) {
+    // column sums of the UNQUANTISED values: 16 rows per wave reduced by DPP-free shuffles, then LDS
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float s = v[j];
+      s += __shfl_xor(s, 4);
+      s += __shfl_xor(s, 8);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if ((threadIdx.x & 63) < 4) csum[threadIdx.x >> 6][tc + j] = s;
+    }
+  }
+  unsigned w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = fminf(fmaxf(v[4 * q + j] * scale, -FMAX), FMAX);
+    w[q] = cvt2<FMT>(f[0], f[1]) | (cvt2<FMT>(f[2], f[3]) << 16);
+  }
+  if (dst && r < rows) {
+    uint8_t* o = dst + r * ld_dst + c0 + tc;
+    if (c0 + tc + 16 <= cols && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+      *reinterpret_cast<uint4*>(o) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (c0 + tc + j < cols) o[j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+    }
+  }
+  if (dst_t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<unsigned*>(&tile[tr][tc + 4 * q]) = w[q];
+  }
+  __syncthreads();
+  if (colsum && threadIdx.x < 64) {
+    const long c = c0 + threadIdx.x;
+    if (c < cols) atomicAdd(colsum + c, csum[0][threadIdx.x] + csum[1][threadIdx.x] + csum[2][threadIdx.x] + csum[3][threadIdx.x]);
+  }
+  if (dst_t) {
+    // thread t writes 16 consecutive source rows of source column (t >> 2): one 16-byte store of dst_t.
+    // Source rows past `rows` hold zeros (the loads above were predicated), which zero-fills the pad.
+    const int oc = threadIdx.x >> 2, orow = (threadIdx.x & 3) * 16;
+    const long c = c0 + oc;
+    if (c < cols) {
+      unsigned o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        o[q] = (unsigned)tile[orow + 4 * q][oc] | ((unsigned)tile[orow + 4 * q + 1][oc] << 8) |
+               ((unsigned)tile[orow + 4 * q + 2][oc] << 16) | ((unsigned)tile[orow + 4 * q + 3][oc] << 24);
+      uint8_t* p = dst_t + c * ld_t + r0 + orow;
+      if (r0 + orow + 16 <= ld_t && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (r0 + orow + j < ld_t) p[j] = (uint8_t)(o[j >> 2] >> (8 * (j & 3)));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int favit_fp8_amax(const void* src, int src_dtype, int64_t rows, int64_t cols, int64_t ld_src, float* amax,
+                              void* stream) {
+  if (!src || !amax || rows <= 0 || cols <= 0 || ld_src < cols) return FAVIT_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  const long total = rows * cols;
+  long nb = (total + 256 * 16 - 1) / (256 * 16);
+  if (nb > 2048) nb = 2048;
+  if (nb < 1) nb = 1;
+  if (src_dtype == FAVIT_F32)
+    hipLaunchKernelGGL(amax_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)src, rows, cols, ld_src, amax);
+  else if (src_dtype == FAVIT_BF16)
+    hipLaunchKernelGGL(amax_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)src, rows, cols, ld_src, amax);
+  else
+    return FAVIT_ERR_INVALID;
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_fp8_quantize(const void* src, int src_dtype, int64_t rows, int64_t cols, int64_t ld_src, void* dst,
+                                  int64_t ld_dst, void* dst_t, int64_t ld_t, int fmt, const float* amax,
+                                  float* scale_inv, float* colsum, void* stream) {
+  if (!src || !amax || !scale_inv || rows <= 0 || cols <= 0 || ld_src < cols) return FAVIT_ERR_INVALID;
+  if (!dst && !dst_t) return FAVIT_ERR_INVALID;
+  if (dst && ld_dst < cols) return FAVIT_ERR_INVALID;
+  if (dst_t && ld_t < rows) return FAVIT_ERR_INVALID;
+  if (fmt != FAVIT_E4M3 && fmt != FAVIT_E5M2) return FAVIT_ERR_INVALID;
+  hipStream_t st = as_stream(stream);
+  // the grid also covers the zero pad of the transposed copy (source rows rows..ld_t-1)
+  const long rcover = dst_t ? (ld_t > rows ? ld_t : rows) : rows;
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rcover + 63) / 64));
+#define FAVIT_Q(T, F)                                                                                              \
+  hipLaunchKernelGGL((quantize_kernel<T, F>), grid, dim3(256), 0, st, (const T*)src, (long)rows, (long)cols,        \
+                     (long)ld_src, (uint8_t*)dst, (long)ld_dst, (uint8_t*)dst_t, (long)ld_t, amax, scale_inv, colsum)
+  if (src_dtype == FAVIT_F32) {
+    if (fmt == FAVIT_E4M3) FAVIT_Q(float, FAVIT_E4M3); else FAVIT_Q(float, FAVIT_E5M2);
+  } else if (src_dtype == FAVIT_BF16) {
+    if (fmt == FAVIT_E4M3) FAVIT_Q(bf16_t, FAVIT_E4M3); else FAVIT_Q(bf16_t, FAVIT_E5M2);
+  } else {
+    return FAVIT_ERR_INVALID;
+  }
+#undef FAVIT_Q
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}

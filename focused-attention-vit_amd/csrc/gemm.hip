@@ -64,6 +64,8 @@ struct KParams {
   int xcd_split;       // 1: 1-D grid of ntiles*nsplit blocks, all tiles of a split on one XCD
   int store_policy;    // cache policy of the epilogue's output stores (store16_policy)
   int dbg;     // experiments only (FAVIT_GEMM_DBG): 1 = skip epilogue, 2 = skip main loop
+  const float* scale_a;   // fp8 operands: device dequantisation factors (or null)
+  const float* scale_b;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -631,7 +633,7 @@ constexpr int WEPI_BYTES = 32 * WEPI_LD * 4;        // 8704 B per wave
 // rows [16*Q, 16*(Q+NI)) of the wave's 64x64 accumulator tile (NI = 1 or 2 groups of 16 rows)
 template <typename InT, typename OutT, int Q, int NI, int NJ = 4, int CB = 0>
 __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4 (&acc)[4][NJ], OutT* C, long mbase,
-                                              long nbase, int lane, float* wl, bool first_split) {
+                                              long nbase, int lane, float* wl, bool first_split, float alpha) {
   const bool fast = p.c_vec && (nbase + 64 <= p.N);
   {
 #pragma unroll
@@ -649,7 +651,7 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
         for (int row = 0; row < 16 * NI; ++row) {
           const long m = mbase + Q * 16 + row;
           if (m < p.M && n < p.N) {
-            float v = fmaf(wl[row * WEPI_LD + lane], p.alpha, bv);
+            float v = fmaf(wl[row * WEPI_LD + lane], alpha, bv);
             if (first_split && p.residual) v += p.residual[m * p.ld_res + n];
             atomicAdd(reinterpret_cast<float*>(C) + m * p.ldc + n, v);
           }
@@ -678,8 +680,8 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
         for (int c4 = 0; c4 < CPL / 4; ++c4) {
           float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
           if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + n + 4 * c4);
-          a[4 * c4] = fmaf(a[4 * c4], p.alpha, b.x); a[4 * c4 + 1] = fmaf(a[4 * c4 + 1], p.alpha, b.y);
-          a[4 * c4 + 2] = fmaf(a[4 * c4 + 2], p.alpha, b.z); a[4 * c4 + 3] = fmaf(a[4 * c4 + 3], p.alpha, b.w);
+          a[4 * c4] = fmaf(a[4 * c4], alpha, b.x); a[4 * c4 + 1] = fmaf(a[4 * c4 + 1], alpha, b.y);
+          a[4 * c4 + 2] = fmaf(a[4 * c4 + 2], alpha, b.z); a[4 * c4 + 3] = fmaf(a[4 * c4 + 3], alpha, b.w);
         }
         auto store_vec = [&](OutT* dst) {
           uint4 raw;
@@ -733,7 +735,7 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
           if (n + c >= p.N) continue;
-          float v = a[c] * p.alpha;
+          float v = a[c] * alpha;
           if (p.bias) v += p.bias[n + c];
           if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n + c] = from_f32<OutT>(v);
           if (p.act == FAVIT_ACT_GELU) v = epi_gelu<InT>(v);
@@ -751,14 +753,39 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
 
 template <typename InT, typename OutT>
 __device__ __forceinline__ void wave_epilogue(const KParams& p, const f32x4 (&acc)[4][4], OutT* C, long mbase,
-                                              long nbase, int lane, float* wl, bool first_split) {
-  wave_epilogue_rows<InT, OutT, 0, 2>(p, acc, C, mbase, nbase, lane, wl, first_split);
-  wave_epilogue_rows<InT, OutT, 2, 2>(p, acc, C, mbase, nbase, lane, wl, first_split);
+                                              long nbase, int lane, float* wl, bool first_split, float alpha) {
+  wave_epilogue_rows<InT, OutT, 0, 2>(p, acc, C, mbase, nbase, lane, wl, first_split, alpha);
+  wave_epilogue_rows<InT, OutT, 2, 2>(p, acc, C, mbase, nbase, lane, wl, first_split, alpha);
 }
 
-template <bool AK, bool BKM, typename OutT>
+// F8 = 0: bf16 operands.  F8 = 1 / 2: fp8 operands (OCP e4m3 B; A e4m3 / e5m2), both k-major: a stage is
+// 64 k-values = the same 64-byte rows, so the LDS images, the DMA pieces and the 16-byte fragment reads
+// are unchanged; a lane's 16 bytes are two 8-byte MFMA operands (k-order inside a stage is permuted
+// identically for A and B, which a contraction does not notice).  Half the L2->LDS and LDS->register
+// bytes per flop of the bf16 form; v_mfma_f32_16x16x32_{fp8,bf8}_fp8 runs at the bf16 MFMA rate.
+template <int F8>
+__device__ __forceinline__ f32x4 mfma_tile(const bf16x8& bfrag, const bf16x8& afrag, f32x4 acc) {
+  if constexpr (F8 == 0) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag, afrag, acc, 0, 0, 0);
+  } else {
+    typedef __attribute__((ext_vector_type(2))) long l64x2;
+    const l64x2 b2 = __builtin_bit_cast(l64x2, bfrag), a2 = __builtin_bit_cast(l64x2, afrag);
+    if constexpr (F8 == 1) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[0], a2[0], acc, 0, 0, 0);
+      return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(b2[1], a2[1], acc, 0, 0, 0);
+    } else {      // first operand = B fragment (e4m3), second = A fragment (e5m2)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(b2[0], a2[0], acc, 0, 0, 0);
+      return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(b2[1], a2[1], acc, 0, 0, 0);
+    }
+  }
+}
+
+template <bool AK, bool BKM, typename OutT, int F8 = 0>
 __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, int z) {
+  static_assert(F8 == 0 || (AK && BKM), "fp8 operands are k-major");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ESZ = F8 ? 1 : 2;                    // operand element size
+  constexpr int SBK = F8 ? 64 : P4_BK;               // k-values per 64-byte stage row
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -766,12 +793,12 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
   const long m0 = (long)(tile / p.tiles_n) * P4_BM;
   const long n0 = (long)(tile % p.tiles_n) * BN;
   const long zo = z / p.batch_inner, zi = z % p.batch_inner;
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
-  const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
+  const char* A = reinterpret_cast<const char*>(p.A) + (zo * p.sAo + zi * p.sAi) * ESZ;
+  const char* Bm = reinterpret_cast<const char*>(p.B) + (zo * p.sBo + zi * p.sBi) * ESZ;
   OutT* C = reinterpret_cast<OutT*>(p.C) + zo * p.sCo + zi * p.sCi;
   const long kbeg = (long)split * p.k_per_split;
   const long kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = p.dbg == 2 ? 0 : (int)((kend - kbeg) / P4_BK);
+  const int nk = p.dbg == 2 ? 0 : (int)((kend - kbeg) / SBK);
   const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0) && (wc == 0);
   f32x4 racc[4];
 #pragma unroll
@@ -787,32 +814,47 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // 3 pieces per wave per stage: 2 of A (16 pieces), 1 of B (8 pieces)
-  const bf16_t* sa[2];
-  const bf16_t* sb;
+  const char* sa[2];
+  const char* sb;
   int da[2], db;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int qa = wave * 2 + j;
-    if (AK) {
-      sa[j] = glds_src32<true>(A, p.lda, m0, p.M, kbeg, qa, lane);
+    if (F8) {
+      const int row = 16 * qa + (lane >> 2), c = (lane & 3) ^ ksw32(row);
+      long i = m0 + row;
+      i = i < p.M ? i : p.M - 1;
+      sa[j] = A + i * p.lda + kbeg + c * 16;
+      da[j] = qa * 1024;
+    } else if (AK) {
+      sa[j] = reinterpret_cast<const char*>(glds_src32<true>(reinterpret_cast<const bf16_t*>(A), p.lda, m0, p.M, kbeg, qa, lane));
       da[j] = qa * 1024;
     } else {
       const int sub = qa >> 3, q = qa & 7;
-      sa[j] = glds_src32<false>(A, p.lda, m0 + sub * 128, p.M, kbeg, q, lane);
+      sa[j] = reinterpret_cast<const char*>(glds_src32<false>(reinterpret_cast<const bf16_t*>(A), p.lda, m0 + sub * 128, p.M, kbeg, q, lane));
       da[j] = sub * (P4_A_BYTES / 2) + q * 1024;
     }
   }
-  sb = glds_src32<BKM>(Bm, p.ldb, n0, p.N, kbeg, wave, lane);
+  if (F8) {
+    const int row = 16 * wave + (lane >> 2), c = (lane & 3) ^ ksw32(row);
+    long i = n0 + row;
+    i = i < p.N ? i : p.N - 1;
+    sb = Bm + i * p.ldb + kbeg + c * 16;
+  } else {
+    sb = reinterpret_cast<const char*>(glds_src32<BKM>(reinterpret_cast<const bf16_t*>(Bm), p.ldb, n0, p.N, kbeg, wave, lane));
+  }
   db = P4_A_BYTES + wave * 1024;
+  const long a_step = AK ? 64 : (long)P4_BK * p.lda * 2;      // bytes per stage
+  const long b_step = BKM ? 64 : (long)P4_BK * p.ldb * 2;
   auto issue = [&](int buf) {
     char* st = smem + buf * P4_STAGE;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + da[j]), 16, 0, 0);
-      sa[j] += AK ? P4_BK : P4_BK * p.lda;
+      sa[j] += a_step;
     }
     __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + db), 16, 0, 0);
-    sb += BKM ? P4_BK : P4_BK * p.ldb;
+    sb += b_step;
   };
 
   if (nk > 0) issue(0);
@@ -835,15 +877,14 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-    if (do_rowsum) {
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma_tile<F8>(bfr[j], af[i], acc[i][j]);
+    if (F8 == 0 && do_rowsum) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) racc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], racc[i], 0, 0, 0);
     }
     cur = cur == 2 ? 0 : cur + 1;
   }
-  if (do_rowsum && lane < 16) {
+  if (F8 == 0 && do_rowsum && lane < 16) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long m = m0 + wr * 64 + i * 16 + lane;
@@ -859,9 +900,14 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
     if (s == 12345.678f) C[0] = from_f32<OutT>(s);
     return;
   }
+  float alpha = p.alpha;
+  if (F8) {
+    if (p.scale_a) alpha *= p.scale_a[0];
+    if (p.scale_b) alpha *= p.scale_b[0];
+  }
   __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
   wave_epilogue<bf16_t, OutT>(p, acc, C, m0 + wr * 64, n0 + wc * 64, lane,
-                              reinterpret_cast<float*>(smem + wave * WEPI_BYTES), split == 0);
+                              reinterpret_cast<float*>(smem + wave * WEPI_BYTES), split == 0, alpha);
 }
 
 template <bool AK, bool BKM, typename OutT>
@@ -869,6 +915,14 @@ __global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_kernel(KParams p) 
   int tile, split;
   tile_and_split(p, tile, split);
   p4_body<AK, BKM, OutT>(p, tile, split, blockIdx.z);
+}
+
+// fp8 operands (F8 = 1: e4m3 x e4m3, 2: e5m2 A x e4m3 B), NT layout only
+template <typename OutT, int F8>
+__global__ __launch_bounds__(P4_THREADS, 4) void gemm_fp8_p4_kernel(KParams p) {
+  int tile, split;
+  tile_and_split(p, tile, split);
+  p4_body<true, true, OutT, F8>(p, tile, split, blockIdx.z);
 }
 
 // Grouped weight-gradient launch: several dW = dY^T.X problems that share the token dimension (the
@@ -1103,8 +1157,15 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   if (!g || !g->A || !g->B || !g->C) return FAVIT_ERR_INVALID;
   if (g->M <= 0 || g->N <= 0 || g->K < 0) return FAVIT_ERR_INVALID;
-  if (g->in_dtype != FAVIT_F32 && g->in_dtype != FAVIT_BF16) return FAVIT_ERR_INVALID;
+  if (g->in_dtype != FAVIT_F32 && g->in_dtype != FAVIT_BF16 && g->in_dtype != FAVIT_FP8) return FAVIT_ERR_INVALID;
   if (g->out_dtype != FAVIT_F32 && g->out_dtype != FAVIT_BF16) return FAVIT_ERR_INVALID;
+  const bool fp8 = g->in_dtype == FAVIT_FP8;
+  if (fp8) {
+    if (!g->a_kmajor || !g->b_kmajor || g->a_rowsum || (g->batch > 1)) return FAVIT_ERR_UNSUPPORTED;
+    if (g->fp8_fmt & ~1) return FAVIT_ERR_UNSUPPORTED;            // B must be e4m3
+    if (g->K <= 0 || (g->K % 64) != 0) return FAVIT_ERR_UNSUPPORTED;
+    if (!aligned(g->A, 16) || !aligned(g->B, 16) || (g->lda % 16) != 0 || (g->ldb % 16) != 0) return FAVIT_ERR_ALIGN;
+  }
   if (g->in_dtype == FAVIT_F32 && g->out_dtype != FAVIT_F32) return FAVIT_ERR_UNSUPPORTED;
   if (g->act == FAVIT_ACT_DGELU && !g->aux_in) return FAVIT_ERR_INVALID;
   if (g->a_rowsum && g->a_kmajor) return FAVIT_ERR_UNSUPPORTED;
@@ -1113,7 +1174,7 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   if (g->a_rowsum && batch != 1) return FAVIT_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
 
-  const int bk = g->in_dtype == FAVIT_BF16 ? BK16 : BK32;
+  const int bk = g->in_dtype == FAVIT_F32 ? BK32 : BK16;
   const long tiles_m = (g->M + BM - 1) / BM, tiles_n = (g->N + BN - 1) / BN;
   const long tiles = tiles_m * tiles_n * batch;
   long splits = g->split_k;
@@ -1123,7 +1184,7 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
     splits = 1;
     // automatic split-K only for the weight-gradient shape (both operands mn-major, K = tokens):
     // forward / input-gradient GEMMs stay single-pass and therefore bitwise deterministic.
-    if (can_split && !g->a_kmajor && !g->b_kmajor && tiles < 256 && g->K >= 8 * bk) {
+    if (can_split && ((!g->a_kmajor && !g->b_kmajor) || fp8) && tiles < 256 && g->K >= 8 * bk) {
       splits = (512 + tiles - 1) / tiles;
       const long max_splits = g->K / (4 * bk);
       if (splits > max_splits) splits = max_splits;
@@ -1134,7 +1195,7 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   // p4-eligible weight-gradient GEMM: pick splits = 8*s (one group of splits per XCD) that fills
   // the 64 workgroup slots of an XCD (32 CUs x 2) best, s <= 4 to bound the atomic traffic.
   bool xcd_split = false;
-  if (g->split_k <= 0 && splits > 1 && g->in_dtype == FAVIT_BF16 && batch == 1 && g->M >= 256) {
+  if (g->split_k <= 0 && splits > 1 && (g->in_dtype == FAVIT_BF16 || fp8) && batch == 1 && g->M >= 256) {
     const long t4 = ((g->M + 255) / 256) * tiles_n;
     double best = -1.0;
     long best_s = 1;
@@ -1174,6 +1235,8 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.ntiles = (int)(tiles_m * tiles_n);
   kp.xcd_split = 0;
   kp.alpha = g->alpha;
+  kp.scale_a = fp8 ? g->scale_a : nullptr;
+  kp.scale_b = fp8 ? g->scale_b : nullptr;
   { const char* e = getenv("FAVIT_GEMM_DBG"); kp.dbg = e ? atoi(e) : 0; }
   // epilogue outputs / residual / aux reads are touched once: non-temporal keeps them from evicting
   // the operand panels the co-resident workgroups share in L2 (fc2: 140 -> 114 us)
@@ -1184,12 +1247,12 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.drop_seed = g->dropout_seed;
   if (kp.drop_thresh && (splits > 1 || batch != 1)) return FAVIT_ERR_UNSUPPORTED;
 
-  const int in_vec = g->in_dtype == FAVIT_BF16 ? 8 : 4;   // elements per 16-B load
+  const int in_vec = fp8 ? 16 : (g->in_dtype == FAVIT_BF16 ? 8 : 4);   // elements per 16-B load
   auto strides_ok = [&](long so, long si, int v) { return batch == 1 || ((so % v) == 0 && (si % v) == 0); };
   kp.a_vec = aligned(g->A, 16) && (g->lda % in_vec) == 0 && strides_ok(g->sAo, g->sAi, in_vec);
   kp.b_vec = aligned(g->B, 16) && (g->ldb % in_vec) == 0 && strides_ok(g->sBo, g->sBi, in_vec);
   const size_t osz = g->out_dtype == FAVIT_BF16 ? 2 : 4;
-  const size_t isz = g->in_dtype == FAVIT_BF16 ? 2 : 4;
+  const size_t isz = g->in_dtype == FAVIT_F32 ? 4 : 2;            // aux_in is bf16 beside fp8 operands
   bool cv = aligned(g->C, 4 * osz) && (g->ldc % 4) == 0 && strides_ok(g->sCo, g->sCi, 4);
   if (g->bias) cv = cv && aligned(g->bias, 16);
   if (g->aux_out) cv = cv && aligned(g->aux_out, 4 * osz) && (g->ld_aux_out % 4) == 0 && batch == 1;
@@ -1204,6 +1267,25 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
     hipLaunchKernelGGL(zero_c_kernel, dim3(zb, 1, batch), dim3(256), 0, st, reinterpret_cast<float*>(g->C), g->M,
                        g->N, g->ldc, g->sCo, g->sCi, batch_inner);
     FAVIT_CHECK_LAUNCH();
+  }
+
+  if (fp8) {
+    // every fp8 problem runs the 256x128 DMA kernel (rows past M / N are clamped, the epilogue guards them)
+    const long t8 = ((g->M + 255) / 256) * tiles_n;
+    dim3 grid8((unsigned)t8, (unsigned)splits, 1u);
+    kp.ntiles = (int)t8;
+    if (xcd_split) {
+      kp.xcd_split = 1;
+      grid8 = dim3((unsigned)(t8 * splits), 1u, 1u);
+    }
+    if ((kps % 64) != 0) return FAVIT_ERR_UNSUPPORTED;
+    const bool a_bf8 = (g->fp8_fmt & 1) != 0;
+    if (g->out_dtype == FAVIT_BF16) {
+      if (a_bf8) return launch_p4(gemm_fp8_p4_kernel<bf16_t, 2>, kp, grid8, st);
+      return launch_p4(gemm_fp8_p4_kernel<bf16_t, 1>, kp, grid8, st);
+    }
+    if (a_bf8) return launch_p4(gemm_fp8_p4_kernel<float, 2>, kp, grid8, st);
+    return launch_p4(gemm_fp8_p4_kernel<float, 1>, kp, grid8, st);
   }
 
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)splits, (unsigned)batch);

@@ -51,10 +51,16 @@ def _st():
 def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias=None, act=ACT_NONE,
          aux_in=None, ld_aux_in=0, aux_out=None, ld_aux_out=0, residual=None, ld_res=0, a_rowsum=None,
          accumulate=False, alpha=1.0, batch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), split_k=0,
-         a_off=0, b_off=0, c_off=0, dropout_p=0.0, dropout_seed=0):
-    """C[m,n] = epilogue(alpha * sum_k A[m,k] B[n,k]).  Offsets/strides are in elements."""
+         a_off=0, b_off=0, c_off=0, dropout_p=0.0, dropout_seed=0, scale_a=None, scale_b=None):
+    """C[m,n] = epilogue(alpha * sum_k A[m,k] B[n,k]).  Offsets/strides are in elements.
+    float8 operands (A e4m3 / e5m2, B e4m3; both k-major): scale_a / scale_b are the device scalars
+    written by fp8_quantize."""
     require_gpu(A, B, Cc)
-    if A.dtype != B.dtype:
+    fp8 = A.dtype in _FP8_DT
+    if fp8:
+        if B.dtype != torch.float8_e4m3fn:
+            raise TypeError("fp8 gemm: B must be float8_e4m3fn")
+    elif A.dtype != B.dtype:
         raise TypeError("gemm operands must share a dtype")
     d = GemmDesc()
     ea, ec = A.element_size(), Cc.element_size()
@@ -74,7 +80,11 @@ def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias
     d.sCo, d.sCi = sC
     d.batch, d.batch_inner = batch, batch_inner
     d.a_kmajor, d.b_kmajor = int(a_kmajor), int(b_kmajor)
-    d.in_dtype, d.out_dtype = dt(A), dt(Cc)
+    d.in_dtype, d.out_dtype = (_abi.FP8 if fp8 else dt(A)), dt(Cc)
+    if fp8:
+        d.fp8_fmt = 1 if A.dtype == torch.float8_e5m2 else 0
+        d.scale_a = scale_a.data_ptr() if scale_a is not None else None
+        d.scale_b = scale_b.data_ptr() if scale_b is not None else None
     d.act = act
     d.accumulate = int(accumulate)
     d.split_k = split_k
@@ -92,7 +102,7 @@ def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias
     e0.record()
     _abi.check(_abi.lib().favit_gemm(C.byref(d), _st()), "favit_gemm")
     e1.record()
-    key = ("bf16" if A.dtype == torch.bfloat16 else "f32") + ("_K" if a_kmajor else "_M") + ("K" if b_kmajor else "M") + \
+    key = ("fp8" if fp8 else "bf16" if A.dtype == torch.bfloat16 else "f32") + ("_K" if a_kmajor else "_M") + ("K" if b_kmajor else "M") + \
           ("_obf16" if Cc.dtype == torch.bfloat16 else "_of32")
     GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, key, (M, N, K, batch)))
 
@@ -132,6 +142,32 @@ def gemm_grouped_tn(problems) -> bool:
         fl = sum(2.0 * p[0].shape[0] * p[0].shape[1] * p[1].shape[1] for p in problems)
         GEMM_TRACE.append((e0, e1, fl, "bf16_MM_of32_grouped", (len(problems),)))
     return True
+
+
+_FP8_DT = (torch.float8_e4m3fn, torch.float8_e5m2)
+
+
+def fp8_quantize(src: torch.Tensor, fmt: torch.dtype, *, want=True, want_t=False, colsum: Optional[torch.Tensor] = None):
+    """Per-tensor scaled conversion of a [rows, cols] fp32 / bf16 matrix to OCP fp8 (`fmt` =
+    torch.float8_e4m3fn | torch.float8_e5m2).  Returns (q [rows, cols] or None, q_t [cols, ld_t] or None
+    with ld_t = rows rounded up to 64 and the pad zero-filled, scale_inv device scalar).  The amax is
+    taken on the device in the same call sequence (no host sync).  colsum [cols] fp32 (optional) gets
+    the column sums of src ADDED (bias gradient)."""
+    require_gpu(src)
+    if src.dim() != 2 or src.stride(1) != 1:
+        raise ValueError("fp8_quantize expects a row-major 2-D matrix")
+    rows, cols = src.shape
+    dev = src.device
+    st = torch.zeros(2, dtype=torch.float32, device=dev)        # [amax, scale_inv]
+    L = _abi.lib()
+    _abi.check(L.favit_fp8_amax(_p(src), dt(src), rows, cols, src.stride(0), _p(st), _st()), "favit_fp8_amax")
+    q = torch.empty((rows, cols), dtype=fmt, device=dev) if want else None
+    ld_t = (rows + 63) // 64 * 64
+    q_t = torch.empty((cols, ld_t), dtype=fmt, device=dev) if want_t else None
+    _abi.check(L.favit_fp8_quantize(_p(src), dt(src), rows, cols, src.stride(0), _p(q), cols, _p(q_t), ld_t,
+                                    _abi.E5M2 if fmt == torch.float8_e5m2 else _abi.E4M3, _p(st),
+                                    C.c_void_p(st.data_ptr() + 4), _p(colsum), _st()), "favit_fp8_quantize")
+    return q, q_t, st[1:2]
 
 
 def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:

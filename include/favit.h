@@ -15,7 +15,8 @@
  *     enqueued asynchronously on it, nothing synchronises, nothing allocates
  *   - return 0 on success, a negative FAVIT_ERR_* otherwise; never throws
  *   - dtype codes: FAVIT_F32 (exact fp32 path, f32 MFMA) / FAVIT_BF16 (bf16 operands,
- *     fp32 accumulation, bf16 MFMA)
+ *     fp32 accumulation, bf16 MFMA) / FAVIT_FP8 (GEMM operands only: OCP e4m3 / e5m2 bytes
+ *     with per-tensor scales, fp32 accumulation, fp8 MFMA)
  *   - kernels are stateless and thread-compatible
  */
 #ifndef FAVIT_H_
@@ -27,9 +28,11 @@
 extern "C" {
 #endif
 
-#define FAVIT_ABI_VERSION 1
+#define FAVIT_ABI_VERSION 2
 
-enum { FAVIT_F32 = 0, FAVIT_BF16 = 1 };
+enum { FAVIT_F32 = 0, FAVIT_BF16 = 1, FAVIT_FP8 = 2 };
+/* OCP 8-bit float formats of gfx950 (NOT the MI300X fnuz encodings) */
+enum { FAVIT_E4M3 = 0, FAVIT_E5M2 = 1 };
 
 enum {
   FAVIT_OK = 0,
@@ -64,6 +67,10 @@ const char* favit_strerror(int code);
  * accumulate=1 (or split_k>1) adds into C with fp32 atomics; C must then be FAVIT_F32.
  * a_rowsum (a_kmajor=0 only): a_rowsum[m] += sum_k A[m,k]  (bias gradient, fused).
  * Batched: z in [0,batch): ptr += (z / batch_inner) * s?o + (z % batch_inner) * s?i.
+ * in_dtype = FAVIT_FP8: A and B hold fp8 bytes (a_fp8_fmt / b_fp8_fmt = FAVIT_E4M3 | FAVIT_E5M2; B must
+ *   be E4M3), both k-major, K a multiple of 64 and 16-byte aligned rows, batch = 1; the true operands
+ *   are A*scale_a[0] and B*scale_b[0] (device scalars written by favit_fp8_quantize, NULL = 1), i.e.
+ *   v = alpha*scale_a*scale_b*acc.  aux_in (DGELU) is bf16 in this mode.
  * ---------------------------------------------------------------------------------- */
 typedef struct favit_gemm_t {
   const void* A;
@@ -85,8 +92,10 @@ typedef struct favit_gemm_t {
   int32_t split_k; /* 0 = library decides */
   float alpha;
   float dropout_p;
-  int32_t reserved_;
+  int32_t fp8_fmt;        /* FAVIT_FP8 only: bit 0 = A is E5M2, bit 1 = B is E5M2 (unsupported) */
   uint64_t dropout_seed;
+  const float* scale_a;   /* FAVIT_FP8 only: device scalars (dequantisation factors) or NULL */
+  const float* scale_b;
 } favit_gemm_t;
 
 int favit_gemm(const favit_gemm_t* g, void* stream);
@@ -97,6 +106,24 @@ int favit_gemm(const favit_gemm_t* g, void* stream);
  * a_rowsum (bias gradient) and accumulate; returns FAVIT_ERR_UNSUPPORTED otherwise (the caller
  * then issues them one by one). */
 int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * FP8 operand preparation (BASELINE.json configs[3] "fp8 MFMA path"; no reference counterpart:
+ * the reference is fp32 only).  Per-tensor scaling, computed on the device:
+ *   favit_fp8_amax:     amax[0] = max(amax[0], max |src[i]|)   (caller zeroes amax first)
+ *   favit_fp8_quantize: q = sat(src * fmax / amax[0]) in OCP e4m3 (fmax 448) or e5m2 (fmax 57344),
+ *                       round-to-nearest-even; scale_inv[0] = amax / fmax (the GEMM's scale_a/b).
+ *     dst   [rows, ld_dst]   same orientation as src (NULL to skip)
+ *     dst_t [cols, ld_t]     transposed copy (NULL to skip); columns rows..ld_t-1 are zero-filled,
+ *                            so ld_t (a multiple of 64) can serve as a padded GEMM K
+ *     colsum [cols] fp32     optional: colsum[c] += sum_r src[r,c] (bias gradient of an fp8 Linear)
+ * src dtype is FAVIT_F32 or FAVIT_BF16, row stride ld_src (elements).
+ * ---------------------------------------------------------------------------------- */
+int favit_fp8_amax(const void* src, int src_dtype, int64_t rows, int64_t cols, int64_t ld_src, float* amax,
+                   void* stream);
+int favit_fp8_quantize(const void* src, int src_dtype, int64_t rows, int64_t cols, int64_t ld_src, void* dst,
+                       int64_t ld_dst, void* dst_t, int64_t ld_t, int fmt, const float* amax, float* scale_inv,
+                       float* colsum, void* stream);
 
 /* dst[i] = (dst_dtype) src[i] */
 int favit_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);

@@ -329,3 +329,70 @@ def test_sppp_kernels_vs_golden(K):
         assert rel_l2(pe, c["posenc_out"]) < 2e-5
     pe = K.sppp_posenc_fwd(torch.from_numpy(SP["posenc_nocentroid_in"]).to(DEV), None)
     assert rel_l2(pe, SP["posenc_nocentroid_out"]) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# fp8 GEMM path (BASELINE.json configs[3]); no reference counterpart -- checked against torch's own
+# OCP float8 conversions and an fp32 matmul of the dequantised operands.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("src_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fmt", [torch.float8_e4m3fn, torch.float8_e5m2])
+@pytest.mark.parametrize("rows,cols", [(64, 64), (197, 384), (577, 96), (50, 130), (1, 16)])
+def test_fp8_quantize_bit_exact_vs_torch(K, src_dtype, fmt, rows, cols):
+    g = torch.Generator(device=DEV).manual_seed(rows * 1000 + cols)
+    x = (_rand((rows, cols), torch.float32, g) * 3.0).to(src_dtype)
+    colsum = torch.zeros(cols, device=DEV)
+    q, qt, sinv = K.fp8_quantize(x, fmt, want=True, want_t=True, colsum=colsum)
+    fmax = 448.0 if fmt == torch.float8_e4m3fn else 57344.0
+    amax = np.float32(x.float().abs().max().item())
+    # IEEE fp32 divisions (torch divides a tensor by a scalar through a reciprocal multiply)
+    assert sinv.item() == float(amax / np.float32(fmax))
+    scale = torch.tensor(float(np.float32(fmax) / amax), dtype=torch.float32, device=DEV)
+    ref = (x.float() * scale).clamp(-fmax, fmax).to(fmt)
+    assert torch.equal(q.view(torch.uint8), ref.view(torch.uint8))
+    ld_t = (rows + 63) // 64 * 64
+    assert qt.shape == (cols, ld_t)
+    assert torch.equal(qt[:, :rows].view(torch.uint8), ref.t().contiguous().view(torch.uint8))
+    assert int(qt[:, rows:].view(torch.uint8).to(torch.int32).abs().sum()) == 0          # zero pad
+    assert rel_l2(colsum, x.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("afmt", [torch.float8_e4m3fn, torch.float8_e5m2])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,Kd", [(256, 128, 64), (300, 200, 128), (1154, 1152, 384), (33, 1000, 768), (5, 7, 64)])
+def test_fp8_gemm_vs_dequantised_fp32_matmul(K, afmt, out_dtype, M, N, Kd):
+    g = torch.Generator(device=DEV).manual_seed(M + N + Kd)
+    a = _rand((M, Kd), torch.bfloat16, g)
+    b = _rand((N, Kd), torch.bfloat16, g)
+    bias = _rand((N,), torch.float32, g)
+    res = _rand((M, N), torch.float32, g) if out_dtype == torch.float32 else None
+    aq, _, sa = K.fp8_quantize(a, afmt)
+    bq, _, sb = K.fp8_quantize(b, torch.float8_e4m3fn)
+    out = torch.empty((M, N), dtype=out_dtype, device=DEV)
+    K.gemm(aq, bq, out, M, N, Kd, Kd, Kd, N, bias=bias, residual=res, ld_res=N, scale_a=sa, scale_b=sb)
+    ref = (aq.float() * sa) @ (bq.float() * sb).t() + bias
+    if res is not None:
+        ref = ref + res
+    assert rel_l2(out.float(), ref) < (2e-5 if out_dtype == torch.float32 else 4e-3)
+    # and the quantisation error itself is what fp8 promises (e4m3: 3 mantissa bits, e5m2: 2)
+    exact = a.float() @ b.float().t() + bias + (res if res is not None else 0)
+    assert rel_l2(out.float(), exact) < (0.06 if afmt == torch.float8_e4m3fn else 0.12)
+
+
+def test_fp8_gemm_split_k_weight_gradient_shape(K):
+    """dW = dY^T X through the NT fp8 kernel: both operands transposed (k = tokens, zero-padded to 64),
+    split-K with fp32 atomics, accumulate into an existing buffer."""
+    g = torch.Generator(device=DEV).manual_seed(9)
+    T, N, Kd = 2 * 577, 384, 128
+    dy = _rand((T, N), torch.bfloat16, g)
+    x = _rand((T, Kd), torch.bfloat16, g)
+    db = torch.zeros(N, device=DEV)
+    _, dyt, sdy = K.fp8_quantize(dy, torch.float8_e5m2, want=False, want_t=True, colsum=db)
+    _, xt, sx = K.fp8_quantize(x, torch.float8_e4m3fn, want=False, want_t=True)
+    Tp = dyt.shape[1]
+    assert Tp % 64 == 0 and xt.shape[1] == Tp
+    dw = torch.ones((N, Kd), device=DEV)
+    K.gemm(dyt, xt, dw, N, Kd, Tp, Tp, Tp, Kd, accumulate=True, scale_a=sdy, scale_b=sx)
+    ref = 1.0 + (dyt.float() * sdy) @ (xt.float() * sx).t()
+    assert rel_l2(dw, ref) < 2e-5
+    assert rel_l2(db, dy.float().sum(0)) < 1e-5
