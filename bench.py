@@ -89,7 +89,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE.json configs[1]: 256)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
+                    help="bf16 = BASELINE.json configs[1] (the headline); fp8 = the configs[3] GEMM path, informational")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("FAVIT_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")

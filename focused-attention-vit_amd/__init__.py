@@ -11,9 +11,9 @@ The math runs in hand-written HIP kernels (``csrc/``) reached through the C ABI 
 ``include/favit.h``; there is no CPU or PyTorch-op fallback.
 """
 from . import _abi
-from .functional import (get_compute_dtype, set_compute_dtype, set_side_stream, set_direct_grads,
+from .functional import (get_compute_dtype, get_compute_mode, set_compute_dtype, set_side_stream, set_direct_grads,
                          invalidate_weight_cache)
 from . import kernels, functional, models
 from . import dp, train
 
-__all__ = ["set_compute_dtype", "get_compute_dtype", "invalidate_weight_cache", "kernels", "functional", "models", "dp", "train", "_abi"]
+__all__ = ["set_compute_dtype", "get_compute_dtype", "get_compute_mode", "invalidate_weight_cache", "kernels", "functional", "models", "dp", "train", "_abi"]

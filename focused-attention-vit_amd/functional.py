@@ -118,12 +118,23 @@ def join_side_stream() -> None:
 
 
 def set_compute_dtype(d) -> None:
-    """'fp32' (exact f32 MFMA path, the parity mode) or 'bf16' (bf16 MFMA, fp32 accumulate)."""
+    """'fp32' (exact f32 MFMA path, the parity mode), 'bf16' (bf16 MFMA, fp32 accumulate) or 'fp8'
+    (BASELINE.json configs[3]: the nn.Linear GEMMs of the encoder blocks run on fp8 MFMA -- e4m3
+    activations / weights, e5m2 gradients, per-tensor scales taken on the device -- everything else as
+    in 'bf16'; patch embedding and classifier head stay bf16)."""
+    fp8 = False
     if isinstance(d, str):
-        d = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[d]
+        fp8 = d == "fp8"
+        d = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+             "fp8": torch.bfloat16}[d]
     if d not in (torch.float32, torch.bfloat16):
-        raise ValueError("compute dtype must be fp32 or bf16")
+        raise ValueError("compute dtype must be fp32, bf16 or fp8")
     _STATE["cdt"] = d
+    _STATE["fp8"] = fp8
+
+
+def get_compute_mode() -> str:
+    return "fp8" if _STATE.get("fp8") else ("bf16" if _STATE["cdt"] == torch.bfloat16 else "fp32")
 
 
 def get_compute_dtype() -> torch.dtype:
@@ -216,18 +227,59 @@ def _mask_u8(mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 # ------------------------------------------------------------------------------------
 # GEMM helpers (nn.Linear forward / backward)
 # ------------------------------------------------------------------------------------
-def lin_fwd(a, w_c, bias, M, N, Kd, out_dtype, *, act=ACT_NONE, residual=None, want_pre=False, drop=(0.0, 0)):
+E4M3, E5M2 = torch.float8_e4m3fn, torch.float8_e5m2
+
+
+def _q8(t: torch.Tensor, fmt: torch.dtype):
+    """(q, q_t, scale_inv, colsum) of a 2-D bf16 matrix, cached on the tensor object: an activation is
+    quantised once for its forward GEMM and its weight-gradient GEMM, a gradient once for dX and dW."""
+    hit = getattr(t, "_favit_q8", None)
+    if hit is not None and hit[0] == (fmt, t._version):
+        return hit[1]
+    colsum = torch.zeros(t.shape[1], dtype=torch.float32, device=t.device) if fmt == E5M2 else None
+    q, qt, sinv = K.fp8_quantize(t, fmt, want=True, want_t=True, colsum=colsum)
+    out = (q, qt, sinv, colsum)
+    try:
+        t._favit_q8 = ((fmt, t._version), out)
+    except AttributeError:                    # pragma: no cover
+        pass
+    return out
+
+
+def _use_fp8(allow, *mats, k_dims=()):
+    """fp8 GEMM applies: fp8 mode, bf16 row-major operands, contraction lengths multiples of 64."""
+    if not (allow and _STATE.get("fp8")):
+        return False
+    return all(m.dtype == torch.bfloat16 and m.dim() == 2 and m.is_contiguous() for m in mats) and \
+        all(k % 64 == 0 for k in k_dims)
+
+
+def lin_fwd(a, w_c, bias, M, N, Kd, out_dtype, *, act=ACT_NONE, residual=None, want_pre=False, drop=(0.0, 0),
+            allow_fp8=True):
     out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     pre = torch.empty((M, N), dtype=out_dtype, device=a.device) if want_pre else None
+    if _use_fp8(allow_fp8, a, w_c, k_dims=(Kd,)):
+        aq, _, sa, _ = _q8(a, E4M3)
+        wq, _, sw, _ = _q8(w_c, E4M3)
+        K.gemm(aq, wq, out, M, N, Kd, Kd, Kd, N, bias=bias, act=act, aux_out=pre, ld_aux_out=N, residual=residual,
+               ld_res=N, dropout_p=drop[0], dropout_seed=drop[1], scale_a=sa, scale_b=sw)
+        return (out, pre) if want_pre else out
     K.gemm(a, w_c, out, M, N, Kd, Kd, Kd, N, bias=bias, act=act, aux_out=pre, ld_aux_out=N, residual=residual,
            ld_res=N, dropout_p=drop[0], dropout_seed=drop[1])
     return (out, pre) if want_pre else out
 
 
-def lin_bwd_x(dy, w_c, M, N, Kd, out_dtype, *, dgelu_pre=None, drop=(0.0, 0)):
+def lin_bwd_x(dy, w_c, M, N, Kd, out_dtype, *, dgelu_pre=None, drop=(0.0, 0), allow_fp8=True):
     """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(pre) * dropout-mask)."""
     dx = torch.empty((M, Kd), dtype=out_dtype, device=dy.device)
-    K.gemm(dy, w_c, dx, M, Kd, N, N, Kd, Kd, b_kmajor=False, act=ACT_DGELU if dgelu_pre is not None else ACT_NONE,
+    act = ACT_DGELU if dgelu_pre is not None else ACT_NONE
+    if _use_fp8(allow_fp8, dy, w_c, k_dims=(N,)) and (dgelu_pre is None or dgelu_pre.dtype == torch.bfloat16):
+        dyq, _, sdy, _ = _q8(dy, E5M2)
+        _, wqt, sw, _ = _q8(w_c, E4M3)                  # [Kd, N]: W^T, k-major over N
+        K.gemm(dyq, wqt, dx, M, Kd, N, N, wqt.stride(0), Kd, act=act, aux_in=dgelu_pre, ld_aux_in=Kd,
+               dropout_p=drop[0], dropout_seed=drop[1], scale_a=sdy, scale_b=sw)
+        return dx
+    K.gemm(dy, w_c, dx, M, Kd, N, N, Kd, Kd, b_kmajor=False, act=act,
            aux_in=dgelu_pre, ld_aux_in=Kd, dropout_p=drop[0], dropout_seed=drop[1])
     return dx
 
@@ -261,7 +313,7 @@ def end_wgrads() -> None:
     _WG["list"] = None
 
 
-def lin_bwd_w(dy, a, M, N, Kd, want_bias=True, wp=None, bp=None):
+def lin_bwd_w(dy, a, M, N, Kd, want_bias=True, wp=None, bp=None, allow_fp8=True):
     """dw[N,K] = dy[M,N]^T @ a[M,K] (fp32, split-K over the tokens), db[N] = column sums of dy (fused).
     If the parameters wp / bp own usable .grad buffers the results are accumulated there and None
     is returned in their place."""
@@ -275,6 +327,19 @@ def lin_bwd_w(dy, a, M, N, Kd, want_bias=True, wp=None, bp=None):
     db = None
     if want_bias:
         db = tb if tb is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
+    if _use_fp8(allow_fp8, dy, a) and Kd % 4 == 0:
+        # both operands transposed (k = tokens, zero-padded to a multiple of 64), split-K fp32 atomics
+        _, dyt, sdy, colsum = _q8(dy, E5M2)
+        _, at, sa, _ = _q8(a, E4M3)
+        Mp = dyt.shape[1]
+        K.gemm(dyt, at, dw, N, Kd, Mp, Mp, Mp, Kd, accumulate=tw is not None, scale_a=sdy, scale_b=sa)
+        if want_bias:
+            db.add_(colsum)
+        if tw is not None:
+            _ready(wp)
+        if tb is not None:
+            _ready(bp)
+        return (None if tw is not None else dw), (None if tb is not None else db)
     if _WG["list"] is not None and dy.dtype == torch.bfloat16:
         # deferred: joins the block's grouped weight-gradient launch
         _WG["list"].append((dy, a, dw, db, tw is not None,
@@ -555,15 +620,15 @@ class LinearOp:
         a = _as_cdt(x.reshape(-1, shp[-1]))
         w_c = wcast(w)
         M, Kd, N = a.shape[0], a.shape[1], w.shape[0]
-        y = lin_fwd(a, w_c, None if b is None else b.detach(), M, N, Kd, torch.float32)
+        y = lin_fwd(a, w_c, None if b is None else b.detach(), M, N, Kd, torch.float32, allow_fp8=False)
         return y.reshape(*shp[:-1], N), (a, w_c, shp, b is not None, (w, b))
 
     def bwd(self, saved, dy, needs):
         a, w_c, shp, has_b, (w, b) = saved
         M, Kd, N = a.shape[0], a.shape[1], w_c.shape[0]
         dy_c = _as_cdt(dy.reshape(M, N))
-        dx = lin_bwd_x(dy_c, w_c, M, N, Kd, torch.float32).reshape(shp) if needs[0] else None
-        dw, db = lin_bwd_w(dy_c, a, M, N, Kd, want_bias=has_b, wp=w, bp=b)
+        dx = lin_bwd_x(dy_c, w_c, M, N, Kd, torch.float32, allow_fp8=False).reshape(shp) if needs[0] else None
+        dw, db = lin_bwd_w(dy_c, a, M, N, Kd, want_bias=has_b, wp=w, bp=b, allow_fp8=False)
         return [dx], [dw, db] if has_b else [dw]
 
 
@@ -580,7 +645,7 @@ class PatchEmbedOp:
         M, Kd = patches.shape
         D = w.shape[0]
         w_c = wcast(w)
-        tok = lin_fwd(patches, w_c, b.detach(), M, D, Kd, torch.float32)
+        tok = lin_fwd(patches, w_c, b.detach(), M, D, Kd, torch.float32, allow_fp8=False)
         return tok.reshape(B, M // B, D), (patches, w_c, (B, Cc, HW), (w, b))
 
     def bwd(self, saved, dy, needs):
@@ -588,10 +653,10 @@ class PatchEmbedOp:
         M, Kd = patches.shape
         D = w_c.shape[0]
         dy_c = _as_cdt(dy.reshape(M, D))
-        dw, db = lin_bwd_w(dy_c, patches, M, D, Kd, wp=w if w.is_leaf else None, bp=b)
+        dw, db = lin_bwd_w(dy_c, patches, M, D, Kd, wp=w if w.is_leaf else None, bp=b, allow_fp8=False)
         dimg = None
         if needs[0]:
-            dpatch = lin_bwd_x(dy_c, w_c, M, D, Kd, torch.float32)
+            dpatch = lin_bwd_x(dy_c, w_c, M, D, Kd, torch.float32, allow_fp8=False)
             dimg = K.patchify_bwd(dpatch, B, Cc, HW, self.P)
         return [dimg], [dw, db]
 

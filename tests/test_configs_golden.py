@@ -152,3 +152,41 @@ def test_gpu_cfg4_vit_mhla_base_577_tokens(favit, mode, tl, tg):
     m, x, y = _base384(favit)
     m.to(DEV)
     _gpu_check(favit, m, m(x.to(DEV)), y, "cfg4", "cfg4/logits", "cfg4/loss", tl, tg)
+
+
+# ------------------------------------------------------------------ fp8 mode (configs[3]: "fp8 MFMA path")
+# The reference is fp32 only, so the fp8 tolerance is OURS, stated here: encoder-block Linear layers in
+# e4m3 (3 mantissa bits, forward) / e5m2 (2 bits, gradients) with per-tensor scales, 12 layers deep:
+# logits within 0.15 rel-L2 of the fp32 reference (random-init logits are ~N(0, 0.3): small signal), loss within
+# 4e-2 (a single-image loss at cfg4), per-parameter gradient norms within 25 %.
+FP8_TOL = dict(logits=0.15, loss=4e-2, gnorm=0.25)
+
+
+def _fp8_check(favit, m, logits, y, key, lkey, losskey):
+    err = rel_l2(logits.detach().float().cpu(), CF[lkey])
+    assert err < FP8_TOL["logits"], err
+    loss = favit.train.cross_entropy(logits, y.to(DEV))
+    assert abs(loss.item() - float(CF[losskey])) < FP8_TOL["loss"] * abs(float(CF[losskey]))
+    loss.backward()
+    worst = _gn_worst(((k, p.grad) for k, p in m.named_parameters()), key)
+    assert worst < FP8_TOL["gnorm"], worst
+    return err, worst
+
+
+@pytest.mark.gpu
+def test_gpu_cfg4_fp8_vit_mhla_base_577_tokens(favit):
+    favit.set_compute_dtype("fp8")
+    assert favit.get_compute_mode() == "fp8"
+    m, x, y = _base384(favit)
+    m.to(DEV)
+    from importlib import import_module
+    Kmod = favit.kernels
+    Kmod.GEMM_TRACE = []
+    try:
+        logits = m(x.to(DEV))
+        keys = {t[3] for t in Kmod.GEMM_TRACE}
+    finally:
+        Kmod.GEMM_TRACE = None
+    assert any(k.startswith("fp8") for k in keys), keys          # the fp8 kernels really ran
+    print("cfg4 fp8 (logits rel, worst gnorm rel):", _fp8_check(favit, m, logits, y, "cfg4", "cfg4/logits", "cfg4/loss"))
+    favit.set_compute_dtype("fp32")

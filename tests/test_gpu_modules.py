@@ -345,3 +345,18 @@ def test_torch_optim_adamw_training_steps(favit, mode, tol):
         ropt.step()
         assert abs(loss.item() - lo.item()) < tol * max(1.0, abs(lo.item())), (step, loss.item(), lo.item())
     assert lo.item() < 2.0        # three lr=1e-2 steps on one batch visibly reduce the loss (starts at ~2.3)
+
+
+def test_cfg2_fp8_mode_within_stated_tolerance(favit):
+    """fp8 mode at BASELINE.json configs[1] shapes (B=2): same stated tolerance as the cfg4 fp8 case
+    (tests/test_configs_golden.py: logits 0.15, loss 2e-2, gradient norms 25 %)."""
+    torch.manual_seed(1234)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384,
+                                                    depth=12, num_heads=6, window_size=7, use_mhla=True)
+    x = torch.randn(2, 3, 224, 224)
+    y = torch.randint(0, 1000, (2,))
+    favit.set_compute_dtype("fp8")
+    try:
+        _model_check(favit, m, x, y, "cfg2", 0.15, 2e-2, 0.25)
+    finally:
+        favit.set_compute_dtype("fp32")
