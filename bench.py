@@ -25,6 +25,7 @@ import torch.distributed as dist
 HBM_PEAK_GBPS = 8000.0
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MFMA_PEAK_TFLOPS = 157.3
+FP8_DENSE_PEAK_TFLOPS = 5000.0
 
 
 def flops_per_image_train(L=197, D=384, depth=12, hd=64, W=7, N=196, P=16, C=3, classes=1000):
@@ -193,7 +194,8 @@ def main():
                 d[2] += 1
             dom = max(fam, key=lambda k: fam[k][0])
             sec, fl, n = fam[dom]
-            peak = BF16_DENSE_PEAK_TFLOPS if dom.startswith("bf16") else F32_MFMA_PEAK_TFLOPS
+            peak = (BF16_DENSE_PEAK_TFLOPS if dom.startswith("bf16") else
+                    FP8_DENSE_PEAK_TFLOPS if dom.startswith("fp8") else F32_MFMA_PEAK_TFLOPS)
             ach = fl / sec / 1e12
             traffic = None           # HBM bytes per launch from the committed PMC passes (profiles/)
             try:

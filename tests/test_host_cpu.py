@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol(favit):
 
 def test_gemm_descriptor_layout_matches_header(favit):
     # 8 pointers + 21 int64 + 9 int32 + 3 x 4-byte + uint64, naturally aligned
-    assert ctypes.sizeof(favit._abi.GemmDesc) == 8 * 8 + 15 * 8 + 9 * 4 + 4 + 4 + 4 + 8
+    assert ctypes.sizeof(favit._abi.GemmDesc) == 8 * 8 + 15 * 8 + 9 * 4 + 4 + 4 + 4 + 8 + 2 * 8      # ABI v2: + scale_a, scale_b
     assert favit._abi.GemmDesc.dropout_seed.offset % 8 == 0
 
 
