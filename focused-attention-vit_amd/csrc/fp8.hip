@@ -11,12 +11,31 @@ constexpr float E5M2_MAX = 57344.0f;
 
 template <typename T>
 __global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ src, long rows, long cols, long ld,
-                                                   float* __restrict__ amax) {
+                                                   float* __restrict__ amax, int vec) {
   float m = 0.f;
   const long total = rows * cols;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / cols, c = i - r * cols;
-    m = fmaxf(m, fabsf(to_f32(src[r * ld + c])));
+  if (vec) {
+    // contiguous matrix, 16-byte aligned, element count a multiple of the vector width: flat 16-byte loads
+    constexpr int VW = 16 / (int)sizeof(T);
+    const long nv = total / VW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+      float v[VW];
+      const uint4 u = reinterpret_cast<const uint4*>(src)[i];
+      if constexpr (sizeof(T) == 4) {
+        v[0] = __uint_as_float(u.x); v[1] = __uint_as_float(u.y); v[2] = __uint_as_float(u.z); v[3] = __uint_as_float(u.w);
+      } else {
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+      }
+#pragma unroll
+      for (int j = 0; j < VW; ++j) m = fmaxf(m, fabsf(v[j]));
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const long r = i / cols, c = i - r * cols;
+      m = fmaxf(m, fabsf(to_f32(src[r * ld + c])));
+    }
   }
   m = wave_max(m);
   __shared__ float part[4];
@@ -54,10 +73,30 @@ __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ src
   const int tr = threadIdx.x >> 2, tc = (threadIdx.x & 3) * 16;
   const long r = r0 + tr;
   float v[16];
+  {
+    const T* rowp = src + r * ld + c0 + tc;
+    if (r < rows && c0 + tc + 16 <= cols && ((reinterpret_cast<uintptr_t>(rowp) & 15) == 0)) {
+      constexpr int NV = 16 * (int)sizeof(T) / 16;        // 16-byte loads for 16 elements
+      unsigned w[4 * NV];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const long c = c0 + tc + j;
-    v[j] = (r < rows && c < cols) ? to_f32(src[r * ld + c]) : 0.f;
+      for (int q = 0; q < NV; ++q) {
+        const uint4 u = reinterpret_cast<const uint4*>(rowp)[q];
+        w[4 * q] = u.x; w[4 * q + 1] = u.y; w[4 * q + 2] = u.z; w[4 * q + 3] = u.w;
+      }
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = __uint_as_float(w[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const long c = c0 + tc + j;
+        v[j] = (r < rows && c < cols) ? to_f32(src[r * ld + c]) : 0.f;
+      }
+    }
   }
   if (colsum) {
     // column sums of the UNQUANTISED values: 16 rows per wave reduced by DPP-free shuffles, then LDS
@@ -131,10 +170,12 @@ extern "C" int favit_fp8_amax(const void* src, int src_dtype, int64_t rows, int6
   long nb = (total + 256 * 16 - 1) / (256 * 16);
   if (nb > 2048) nb = 2048;
   if (nb < 1) nb = 1;
+  const int esz = src_dtype == FAVIT_F32 ? 4 : 2;
+  const int vec = (ld_src == cols) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && ((total * esz) % 16 == 0);
   if (src_dtype == FAVIT_F32)
-    hipLaunchKernelGGL(amax_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)src, rows, cols, ld_src, amax);
+    hipLaunchKernelGGL(amax_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)src, rows, cols, ld_src, amax, vec);
   else if (src_dtype == FAVIT_BF16)
-    hipLaunchKernelGGL(amax_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)src, rows, cols, ld_src, amax);
+    hipLaunchKernelGGL(amax_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)src, rows, cols, ld_src, amax, vec);
   else
     return FAVIT_ERR_INVALID;
   FAVIT_CHECK_LAUNCH();
