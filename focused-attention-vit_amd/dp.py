@@ -82,6 +82,7 @@ class GradSync:
         self._handles = []
         self._launched = [False] * len(self.buckets)
         self._hooks = []
+        self.defer = False
         self._index = {id(p): i for i, p in enumerate(flat.params)}
         if self.world > 1:
             for i, p in enumerate(flat.params):
@@ -97,6 +98,8 @@ class GradSync:
 
     def _make_hook(self, i):
         def hook(_p):
+            if self.defer:             # graph capture / replay: finish() launches every bucket afterwards
+                return
             b = self._bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] == 0:

@@ -204,6 +204,9 @@ def wcast(w: torch.Tensor) -> torch.Tensor:
 
 def _seed() -> int:
     # drawn from torch's CPU generator: reproducible under torch.manual_seed, no device sync
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("dropout inside a captured HIP graph: the seed is a kernel argument and would be frozen "
+                           "into the graph (train.GraphedStep needs dropout = 0)")
     return int(torch.empty((), dtype=torch.int64).random_().item())
 
 

@@ -113,3 +113,47 @@ def train_step(model, images, labels, opt: FusedAdamW):
     loss.backward()
     opt.step()
     return loss
+
+
+class GraphedStep:
+    """zero_grad -> forward -> cross-entropy -> backward of one training step captured ONCE as a HIP graph
+    and replayed per step; the gradient all-reduce and the fused AdamW run eagerly after each replay.
+
+    For the small-token configurations (SPPP+MHLA: 17 tokens per image) a step is ~600 kernel launches
+    of a few microseconds each and the Python launch path, not the GPU, sets the step time; a replayed
+    graph removes that.  Requirements: FusedAdamW (its bf16 weight mirror is refreshed by kernels, not by
+    host-side caching), fixed shapes, no dropout in training mode (dropout seeds are kernel arguments
+    and would be frozen into the graph), and for SPPP models ``model.assume_num_tokens`` set (the
+    per-forward token-count check is a host sync)."""
+
+    def __init__(self, model: torch.nn.Module, opt: FusedAdamW, images: torch.Tensor, labels: torch.Tensor,
+                 warmup: int = 3):
+        if K.GEMM_TRACE is not None:
+            raise RuntimeError("GraphedStep: disable kernels.GEMM_TRACE (event records cannot be captured)")
+        self.model, self.opt = model, opt
+        self.x, self.y = images.clone(), labels.clone()
+        syncs = [g["sync"] for g in opt.groups if g["sync"] is not None]
+        for s in syncs:
+            s.defer = True
+        self._syncs = syncs
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up off the capture stream (lazy kernel attributes, allocator)
+            for _ in range(max(1, warmup)):
+                opt.zero_grad()
+                cross_entropy(model(self.x), self.y).backward()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            opt.zero_grad()
+            self.loss = cross_entropy(model(self.x), self.y)
+            self.loss.backward()
+
+    def __call__(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        if images is not self.x:
+            self.x.copy_(images, non_blocking=True)
+        if labels is not self.y:
+            self.y.copy_(labels, non_blocking=True)
+        self.graph.replay()
+        self.opt.step()            # eager: launches every deferred all-reduce bucket, then AdamW
+        return self.loss
