@@ -360,3 +360,37 @@ def test_cfg2_fp8_mode_within_stated_tolerance(favit):
         _model_check(favit, m, x, y, "cfg2", 0.15, 2e-2, 0.25)
     finally:
         favit.set_compute_dtype("fp32")
+
+
+def test_graphed_step_matches_eager_steps(favit):
+    """train.GraphedStep (forward + backward replayed from a captured HIP graph, optimizer eager) walks the
+    same trajectory as eager train_step calls: same losses, same weights."""
+    favit.set_compute_dtype("bf16")
+
+    def build():
+        torch.manual_seed(11)
+        m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64,
+                                                        depth=2, num_heads=4, use_mhla=True).to(DEV).train()
+        opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=1e-3), lr=1e-3, weight_decay=0.05, distributed=False)
+        return m, opt
+    g = torch.Generator(device=DEV).manual_seed(2)
+    xs = [torch.randn(8, 3, 32, 32, device=DEV, generator=g) for _ in range(3)]
+    ys = [torch.randint(0, 10, (8,), device=DEV, generator=g) for _ in range(3)]
+    m1, o1 = build()
+    eager = [favit.train.train_step(m1, x, y, o1).item() for x, y in zip(xs, ys)]
+    m2, o2 = build()
+    step = favit.train.GraphedStep(m2, o2, xs[0], ys[0])
+    graphed = [step(x, y).item() for x, y in zip(xs, ys)]
+    # deterministic kernels on this path (no split-K at these sizes would differ): tiny tolerance for atomics
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) < 2e-3 * max(1.0, abs(a)), (eager, graphed)
+    w1 = torch.cat([p.detach().flatten() for p in m1.parameters()])
+    w2 = torch.cat([p.detach().flatten() for p in m2.parameters()])
+    assert rel_l2(w2.cpu(), w1.cpu()) < 1e-3
+    # dropout cannot be captured (its seed is a kernel argument)
+    torch.manual_seed(11)
+    m3 = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2,
+                                                    num_heads=4, use_mhla=True, dropout=0.1).to(DEV).train()
+    o3 = favit.train.FusedAdamW(favit.train.param_groups(m3, lr=1e-3), lr=1e-3, distributed=False)
+    with pytest.raises(RuntimeError):
+        favit.train.GraphedStep(m3, o3, xs[0], ys[0], warmup=1)
