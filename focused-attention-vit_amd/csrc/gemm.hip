@@ -925,6 +925,113 @@ __global__ __launch_bounds__(P4_THREADS, 4) void gemm_fp8_p4_kernel(KParams p) {
   p4_body<true, true, OutT, F8>(p, tile, split, blockIdx.z);
 }
 
+// --------------------------------------------------------------------------------------
+// bf16 kernel "p7": 256x256 tile, SIXTEEN waves (4x4, 64x64 each), BK = 32, three 32-KiB stages
+// (96 KiB -> one 1024-thread workgroup per CU: the same 4 waves/SIMD and 128 VGPRs as two p4
+// workgroups).  The operand stream per flop drops by a third (L2->LDS intensity 128 vs 85 flop/B),
+// which is what bounds the p4 main loop; the price is that all sixteen waves share one barrier and
+// nothing overlaps the epilogue.  Measured (tools/gemm_bench.py, BASE=1): +4..9 % on NT problems with
+// K >= 768 (8192^3: 1011 -> 1106 TF; ViT-Base qkv / fc1 / fc2), nothing at K = 384 (the epilogue is
+// half of those launches), and -10 % with a mn-major B operand -- so it serves NT, K >= 512, N a
+// multiple of 256 only.  Epilogue: wave-private LDS transpose in 16-row passes (69.6 KiB).
+// --------------------------------------------------------------------------------------
+constexpr int P7_THREADS = 1024;
+constexpr int P7_BN = 256;
+constexpr int P7_B_BYTES = 256 * 64;                 // 16 KiB
+constexpr int P7_STAGE = P4_A_BYTES + P7_B_BYTES;    // 32 KiB
+constexpr int P7_LDS = 3 * P7_STAGE;                 // 98304
+constexpr int WEPI_Q_BYTES = 16 * WEPI_LD * 4;       // 4352 B per wave
+
+template <typename OutT>
+__global__ __launch_bounds__(P7_THREADS) void gemm_bf16_p7_kernel(KParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long m0 = (long)(tile / p.tiles_n) * P4_BM;
+  const long n0 = (long)(tile % p.tiles_n) * P7_BN;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B);
+  OutT* C = reinterpret_cast<OutT*>(p.C);
+  const int nk = p.dbg == 2 ? 0 : (int)(p.K / P4_BK);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // one 1-KiB piece of A (16 pieces) and one of B (16 pieces) per wave and stage
+  const char* sa = reinterpret_cast<const char*>(glds_src32<true>(A, p.lda, m0, p.M, 0, wave, lane));
+  const char* sb = reinterpret_cast<const char*>(glds_src32<true>(Bm, p.ldb, n0, p.N, 0, wave, lane));
+  const int da = wave * 1024, db = P4_A_BYTES + wave * 1024;
+  const long b_step = 64;
+  auto issue = [&](int buf) {
+    char* st = smem + buf * P7_STAGE;
+    __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(st + da), 16, 0, 0);
+    sa += 64;
+    __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + db), 16, 0, 0);
+    sb += b_step;
+  };
+
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);
+    const char* st = smem + cur * P7_STAGE;
+    const char* lb = st + P4_A_BYTES;
+    const int rb = wc * 64;
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = load_frag32<true>(st, wr * 64 + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = load_frag32<true>(lb, rb + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  if (p.dbg == 1) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 12345.678f) C[0] = from_f32<OutT>(s);
+    return;
+  }
+  __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
+  float* wl = reinterpret_cast<float*>(smem + wave * WEPI_Q_BYTES);
+  const long mb = m0 + wr * 64, nb = n0 + wc * 64;
+  wave_epilogue_rows<bf16_t, OutT, 0, 1>(p, acc, C, mb, nb, lane, wl, true, p.alpha);
+  wave_epilogue_rows<bf16_t, OutT, 1, 1>(p, acc, C, mb, nb, lane, wl, true, p.alpha);
+  wave_epilogue_rows<bf16_t, OutT, 2, 1>(p, acc, C, mb, nb, lane, wl, true, p.alpha);
+  wave_epilogue_rows<bf16_t, OutT, 3, 1>(p, acc, C, mb, nb, lane, wl, true, p.alpha);
+}
+
+template <typename Kn>
+int launch_p7(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
+  static const void* seen[8];
+  static int nseen = 0;
+  const void* kptr = reinterpret_cast<const void*>(kernel);
+  bool known = false;
+  for (int i = 0; i < nseen; ++i) known = known || seen[i] == kptr;
+  if (!known) {
+    (void)hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, P7_LDS);
+    if (nseen < 8) seen[nseen++] = kptr;
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(P7_THREADS), P7_LDS, st, kp);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
 // Grouped weight-gradient launch: several dW = dY^T.X problems that share the token dimension (the
 // four Linear layers of one transformer block) run as ONE grid.  Their tiles together fill the 64
 // workgroup slots of an XCD with a single K-split per XCD (8 splits in all instead of 24 each), which
@@ -1297,6 +1404,18 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   const bool no_p4 = getenv("FAVIT_GEMM_NO_P4") != nullptr;
   // large GEMMs: 256x128 tiles, 2 workgroups per CU, wave-private epilogue (plain or fp32-atomic)
   const long t4 = ((g->M + 255) / 256) * tiles_n;
+  // 256x256 tiles: single-pass NT problems with K >= 512 and N a multiple of 256 (the D = 768 forward GEMMs)
+  const bool no_p7 = getenv("FAVIT_GEMM_NO_P7") != nullptr;
+  if (glds_ok && !force128 && !no_p4 && !no_p7 && splits == 1 && !atomic && batch == 1 && g->a_kmajor && g->b_kmajor &&
+      g->M >= 1024 && (g->N % P7_BN) == 0 && (g->K % P4_BK) == 0 && g->K >= 512 &&
+      ((g->M + 255) / 256) * (g->N / P7_BN) >= 256) {
+    KParams k7 = kp;
+    k7.tiles_n = (int)(g->N / P7_BN);
+    k7.ntiles = (int)(((g->M + 255) / 256) * k7.tiles_n);
+    dim3 grid7((unsigned)k7.ntiles, 1u, 1u);
+    if (g->out_dtype == FAVIT_BF16) return launch_p7(gemm_bf16_p7_kernel<bf16_t>, k7, grid7, st);
+    return launch_p7(gemm_bf16_p7_kernel<float>, k7, grid7, st);
+  }
   if (glds_ok && !force128 && !no_p4 && (g->K % P4_BK) == 0 && (kps % P4_BK) == 0 &&
       ((splits == 1 && g->M >= 1024 && t4 * batch >= 256) || (xcd_split && splits > 1))) {
     dim3 grid4((unsigned)t4, (unsigned)splits, (unsigned)batch);

@@ -396,3 +396,41 @@ def test_fp8_gemm_split_k_weight_gradient_shape(K):
     ref = 1.0 + (dyt.float() * sdy) @ (xt.float() * sx).t()
     assert rel_l2(dw, ref) < 2e-5
     assert rel_l2(db, dy.float().sum(0)) < 1e-5
+
+
+def _abi():
+    import importlib
+    return importlib.import_module("focused-attention-vit_amd")._abi
+
+
+@pytest.mark.parametrize("bk", [True, False])
+@pytest.mark.parametrize("out_dtype,epi", [(torch.bfloat16, "gelu"), (torch.bfloat16, "dgelu"), (torch.float32, "res")])
+def test_gemm_256x256_tile_kernel(K, bk, out_dtype, epi):
+    """The 16-wave 256x256-tile kernel (NT, K >= 512, N multiple of 256, >= 256 tiles) with its fused epilogues and a
+    ragged M; the mn-major-B twin of each case runs the 256x128 kernel on the same shape."""
+    g = torch.Generator(device=DEV).manual_seed(77)
+    M, N, Kd = 8192 + 40, 2048, 544
+    a = _rand((M, Kd), torch.bfloat16, g)
+    b = _rand((N, Kd) if bk else (Kd, N), torch.bfloat16, g)
+    bias = _rand((N,), torch.float32, g)
+    out = torch.empty((M, N), dtype=out_dtype, device=DEV)
+    ref = a.float() @ (b.float().t() if bk else b.float())
+    kw = dict(b_kmajor=bk)
+    ldb = Kd if bk else N
+    if epi == "gelu":
+        pre = torch.empty_like(out)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, bias=bias, act=_abi().ACT_GELU, aux_out=pre, ld_aux_out=N, **kw)
+        ref = ref + bias
+        assert rel_l2(pre.float(), ref) < 1e-2
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == "dgelu":
+        pre = _rand((M, N), torch.bfloat16, g)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, act=_abi().ACT_DGELU, aux_in=pre, ld_aux_in=N, **kw)
+        x = pre.float().requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        ref = ref * x.grad
+    else:
+        res = _rand((M, N), torch.float32, g)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, bias=bias, residual=res, ld_res=N, **kw)
+        ref = ref + bias + res
+    assert rel_l2(out.float(), ref) < (1e-2 if out_dtype == torch.bfloat16 else 2e-5)

@@ -50,3 +50,16 @@ run("bwd dWqkv TN [1152,384]", lambda: K.gemm(o_qkv, x, dwq, 3 * D, D, T, 3 * D,
 big = 8192
 a8 = rnd(big, big); b8 = rnd(big, big); c8 = torch.empty(big, big, device=dev, dtype=bf)
 run("square 8192^3 NT", lambda: K.gemm(a8, b8, c8, big, big, big, big, big, big), 2 * big ** 3)
+
+if os.environ.get("BASE"):
+    # ViT-MHLA-Base 384/p16 (BASELINE.json configs[3] per-GPU shape: 64 images x 577 tokens, D = 768)
+    Tb, Db = 64 * 577, 768
+    xb = rnd(Tb, Db); hb = rnd(Tb, 4 * Db)
+    wq = rnd(3 * Db, Db); wf1 = rnd(4 * Db, Db); wf2 = rnd(Db, 4 * Db)
+    oq = torch.empty(Tb, 3 * Db, device=dev, dtype=bf); oh = torch.empty(Tb, 4 * Db, device=dev, dtype=bf)
+    od = torch.empty(Tb, Db, device=dev); resb = torch.randn(Tb, Db, device=dev); odb = torch.empty(Tb, Db, device=dev, dtype=bf)
+    run("base qkv  NT K=768 N=2304", lambda: K.gemm(xb, wq, oq, Tb, 3 * Db, Db, Db, Db, 3 * Db), 2 * Tb * 3 * Db * Db)
+    run("base fc1  NT K=768 N=3072", lambda: K.gemm(xb, wf1, oh, Tb, 4 * Db, Db, Db, Db, 4 * Db, act=A.ACT_GELU), 2 * Tb * 4 * Db * Db)
+    run("base fc2  NT K=3072 N=768 res", lambda: K.gemm(hb, wf2, od, Tb, Db, 4 * Db, 4 * Db, 4 * Db, Db, residual=resb, ld_res=Db), 2 * Tb * 4 * Db * Db)
+    run("base dXn2 NN K=3072 N=768", lambda: K.gemm(hb, wf1, odb, Tb, Db, 4 * Db, 4 * Db, Db, Db, b_kmajor=False), 2 * Tb * 4 * Db * Db)
+    run("base dX   NN K=2304 N=768", lambda: K.gemm(oq, wq, odb, Tb, Db, 3 * Db, 3 * Db, Db, Db, b_kmajor=False), 2 * Tb * 3 * Db * Db)
