@@ -65,7 +65,10 @@ def _ready(*params):
 # Optional side stream for weight-gradient GEMMs (dW = dY^T.X does not feed the backward chain).
 # Measured on MI355X it bought nothing for this workload (21.42 vs 21.35 ms/step: every GEMM already
 # fills the chip), so it is OFF by default; kept because it is the natural hook for overlapping the
-# DP all-reduce of early buckets with compute on multi-GPU runs.
+# DP all-reduce of early buckets with compute on multi-GPU runs.  Also measured: the small latency-bound
+# latent_proj fold kernels (36 per step, 15-40 us) moved to this stream (forward folds launched up
+# front, backward folds under the LayerNorm backward) -- no gain either (18.7 vs 18.3 ms/step): every
+# cross-stream dependency costs a barrier packet of several microseconds, about what the overlap saves.
 # ------------------------------------------------------------------------------------
 _SIDE = {"enabled": False, "stream": None, "active": False, "pending": [], "used": False}
 
