@@ -434,3 +434,148 @@ def test_gemm_256x256_tile_kernel(K, bk, out_dtype, epi):
         K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, bias=bias, residual=res, ld_res=N, **kw)
         ref = ref + bias + res
     assert rel_l2(out.float(), ref) < (1e-2 if out_dtype == torch.bfloat16 else 2e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# Seeded random sweeps: every dispatch branch of favit_gemm (register-staged / DMA 128x128 / 256x128 /
+# 256x256 / split-K / fp32) is reached by some shape below; ragged sizes and odd leading dimensions.
+# ---------------------------------------------------------------------------------------------
+def _sweep_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:       # tiny / ragged
+            M, N, Kd = int(rs.randint(1, 200)), int(rs.randint(1, 200)), int(rs.randint(1, 200))
+        elif kind == 1:     # DMA-eligible mid sizes (K multiple of 64)
+            M, N, Kd = int(rs.randint(100, 1500)), int(rs.randint(8, 160) * 8), int(rs.randint(1, 8) * 64)
+        elif kind == 2:     # big-M (256x128 / 256x256 kernels)
+            M, N, Kd = int(rs.randint(20000, 40000)), int(rs.choice([256, 384, 512, 1000, 1152])), int(rs.choice([64, 96, 512, 544]))
+        else:               # weight-gradient shape (long K, split-K)
+            M, N, Kd = int(rs.choice([64, 192, 384, 1000])), int(rs.choice([48, 192, 384])), int(rs.randint(3000, 20000))
+        out.append((M, N, Kd, bool(rs.randint(2)), bool(rs.randint(2)), int(rs.randint(3)), i))
+    return out
+
+
+@pytest.mark.parametrize("M,N,Kd,ak,bk,variant,idx", _sweep_cases(48, 2024))
+def test_gemm_random_sweep(K, M, N, Kd, ak, bk, variant, idx):
+    dtype = torch.bfloat16 if idx % 3 else torch.float32
+    g = torch.Generator(device=DEV).manual_seed(1000 + idx)
+    pad_a, pad_b = (0, 8)[idx % 2], (8, 0)[idx % 2]           # leading dimensions larger than the row
+    Afull = _rand(((M, Kd + pad_a) if ak else (Kd, M + pad_a)), dtype, g)
+    Bfull = _rand(((N, Kd + pad_b) if bk else (Kd, N + pad_b)), dtype, g)
+    A = Afull[:, :Kd] if ak else Afull[:, :M]
+    B = Bfull[:, :Kd] if bk else Bfull[:, :N]
+    Af = (A.float() if ak else A.float().t()).double()
+    Bf = (B.float() if bk else B.float().t()).double()
+    ref = Af @ Bf.t()
+    bias = _rand((N,), torch.float32, g)
+    if variant == 0:        # plain fp32 output
+        C = torch.empty((M, N), dtype=torch.float32, device=DEV)
+        K.gemm(Afull, Bfull, C, M, N, Kd, Afull.stride(0), Bfull.stride(0), N, a_kmajor=ak, b_kmajor=bk)
+        assert rel_l2(C, ref) < 3e-5
+    elif variant == 1:      # bias, output in the input dtype
+        C = torch.empty((M, N), dtype=dtype, device=DEV)
+        K.gemm(Afull, Bfull, C, M, N, Kd, Afull.stride(0), Bfull.stride(0), N, a_kmajor=ak, b_kmajor=bk, bias=bias)
+        assert rel_l2(C.float(), ref + bias.double()) < (3e-5 if dtype == torch.float32 else 6e-3)
+    else:                   # accumulate into an existing fp32 buffer with alpha
+        C0 = _rand((M, N), torch.float32, g)
+        C = C0.clone()
+        K.gemm(Afull, Bfull, C, M, N, Kd, Afull.stride(0), Bfull.stride(0), N, a_kmajor=ak, b_kmajor=bk,
+               accumulate=True, alpha=0.25)
+        assert rel_l2(C, C0.double() + 0.25 * ref) < 3e-5
+
+
+def _attn_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        W = int(rs.choice([3, 5, 7, 9, 11]))
+        hd = int(rs.choice([16, 32, 64, 128]))
+        L = int(rs.choice([1, 2, 3, W - 1, W, W + 1, 16, 17, 31, 50, 64, 65, 130, 197, 300])) or 1
+        out.append((max(1, L), W, hd, int(rs.randint(1, 4)), int(rs.randint(1, 4)), bool(rs.randint(2)), i))
+    return out
+
+
+@pytest.mark.parametrize("L,W,hd,B,H,masked,idx", _attn_cases(40, 7))
+def test_mhla_core_random_sweep(K, L, W, hd, B, H, masked, idx):
+    """Random (L, W, hd, B, H, mask) against the gather-based window restatement, fwd + bwd, both dtypes."""
+    from oracle import favit_oracle as O
+    dtype = torch.bfloat16 if idx % 2 else torch.float32
+    D = H * hd
+    g = torch.Generator(device=DEV).manual_seed(500 + idx)
+    qkv = _rand((B * L, 3 * D), dtype, g)
+    dout = _rand((B * L, D), dtype, g)
+    mask = None
+    if masked:
+        mask = (torch.rand(B, L, L, generator=g, device=DEV) > 0.4)
+        mask |= torch.eye(L, dtype=torch.bool, device=DEV)
+        mask = mask.to(torch.uint8).contiguous()
+    out = K.mhla_attn_fwd(qkv, B, L, H, hd, W, mask)
+    dqkv = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask)
+    idxs = torch.from_numpy(O.window_indices(L, W)).to(DEV)
+    t = qkv.float().reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4).detach().clone().requires_grad_(True)
+    q, k, v = t[0], t[1], t[2]
+    kw, vw = k[:, :, idxs], v[:, :, idxs]
+    s = (q.unsqueeze(3) @ kw.transpose(-2, -1)).squeeze(3) / (hd ** 0.5)
+    if mask is not None:
+        wm = torch.gather(mask[:, None].expand(B, H, L, L), 3, idxs[None, None].expand(B, H, L, W))
+        s = s.masked_fill(wm == 0, float("-inf"))
+    o = (torch.softmax(s, -1).unsqueeze(3) @ vw).squeeze(3).transpose(1, 2).reshape(B * L, D)
+    assert rel_l2(out.float(), o) < _tol(dtype)
+    o.backward(dout.float())
+    gref = t.grad.permute(1, 3, 0, 2, 4).reshape(B * L, 3 * D)
+    assert rel_l2(dqkv.float(), gref) < (5e-5 if dtype == torch.float32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_sppp_map_pool_centroids_random_label_maps(K, seed):
+    """Random label maps (blocky noise: ties inside patches, labels that never dominate a patch, gaps in the
+    label range) against the oracle: the integer work (dominant label with smallest-label tie-break, first
+    appearance rank) must be bit-exact; pooling / centroids to fp32 rounding."""
+    from oracle import favit_oracle as O
+    rs = np.random.RandomState(seed)
+    P = int(rs.choice([4, 8, 16]))
+    g = int(rs.choice([2, 5, 14]))
+    img = P * g
+    S = int(rs.choice([4, 9, 16]))
+    cell = int(rs.choice([1, 2, P // 2, P, 2 * P]))
+    base = rs.randint(0, S + 3, size=((img + cell - 1) // cell, (img + cell - 1) // cell))     # labels may exceed S
+    seg = np.kron(base, np.ones((cell, cell), dtype=np.int64))[:img, :img].astype(np.int64)
+    mapping = O.map_patches(seg, img, P)
+    rank_ref = np.full(g * g, -1, dtype=np.int64)
+    for r, (_, idx) in enumerate(mapping.items()):
+        rank_ref[idx] = r
+    segt = torch.from_numpy(seg).to(DEV)
+    rank, ntok, perm, offs, dom = K.sppp_map_patches(segt[None], P)
+    np.testing.assert_array_equal(rank[0].cpu().numpy(), rank_ref)
+    R = int(ntok[0].item())
+    assert R == len(mapping)
+    D = 32
+    emb = torch.randn(g * g, D, generator=torch.Generator().manual_seed(seed))
+    for kind, kname in enumerate(("mean", "max", "attention")):
+        ref = O.pool(emb.clone(), mapping, kname)
+        out, _ = K.sppp_pool_fwd(emb.to(DEV)[None].contiguous(), perm, offs, kind, R)
+        assert rel_l2(out[0], ref) < 2e-5, kname
+    cent = K.sppp_centroids(segt[None], S)
+    assert rel_l2(cent, O.superpixel_centroids(seg[None], S)) < 2e-5
+
+
+@pytest.mark.parametrize("idx", list(range(16)))
+def test_layernorm_random_sweep(K, idx):
+    rs = np.random.RandomState(100 + idx)
+    rows, D = int(rs.randint(1, 700)), int(rs.randint(1, 400) * 4)
+    dtype = torch.bfloat16 if idx % 2 else torch.float32
+    g = torch.Generator(device=DEV).manual_seed(idx)
+    x = torch.randn((rows, D), generator=g, device=DEV) * float(rs.uniform(0.1, 30)) + float(rs.uniform(-5, 5))
+    gam, bet = torch.randn(D, generator=g, device=DEV), torch.randn(D, generator=g, device=DEV)
+    y, mu, rstd = K.layernorm_fwd(x, D, gam, bet, rows, D, dtype)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    assert rel_l2(y.float(), yr) < _tol(dtype)
+    dy = _rand((rows, D), dtype, g)
+    dx, _, dg, db = K.layernorm_bwd(dy, x, D, gam, mu, rstd, rows, D)
+    yr.backward(dy.float())
+    assert rel_l2(dx, xr.grad) < 5e-5
+    assert rel_l2(dg, gr.grad) < 5e-5 and rel_l2(db, br.grad) < 5e-5
