@@ -394,3 +394,27 @@ def test_graphed_step_matches_eager_steps(favit):
     o3 = favit.train.FusedAdamW(favit.train.param_groups(m3, lr=1e-3), lr=1e-3, distributed=False)
     with pytest.raises(RuntimeError):
         favit.train.GraphedStep(m3, o3, xs[0], ys[0], warmup=1)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp8"])
+def test_fused_loop_overfits_a_small_batch(favit, mode):
+    """End-to-end sanity of the hot loop (zero_grad -> forward -> CE -> backward -> fused AdamW): a small
+    ViT-MHLA memorises 16 random images; with the name-based groups of the experiments (5x lr on latent_proj)."""
+    favit.set_compute_dtype(mode)
+    try:
+        torch.manual_seed(21)
+        m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=128, depth=2,
+                                                        num_heads=2, use_mhla=True).to(DEV).train()
+        opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=2e-3), lr=2e-3, weight_decay=0.0, distributed=False)
+        x = torch.randn(16, 3, 32, 32, device=DEV)
+        y = torch.arange(16, device=DEV) % 10
+        first = None
+        for _ in range(60):
+            loss = favit.train.train_step(m, x, y, opt)
+            first = loss.item() if first is None else first
+        assert first > 2.0 and loss.item() < 0.3, (first, loss.item())
+        m.eval()
+        with torch.no_grad():
+            assert (m(x).argmax(1) == y).float().mean().item() > 0.9
+    finally:
+        favit.set_compute_dtype("fp32")
