@@ -56,7 +56,7 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(pkg, model, batch=16, steps=12):
+def cpu_baseline(pkg, model, batch=16, steps=24):
     """The CPU oracle (oracle/favit_oracle.py, a port of the reference's PyTorch-CPU path) timed on
     this box's host cores: same model config, B=16, 1 warm-up + `steps` timed fwd+bwd steps."""
     from oracle import favit_oracle as O
