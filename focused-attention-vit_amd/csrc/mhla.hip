@@ -924,12 +924,13 @@ __device__ __forceinline__ void fold_tile_gemm(const float* At, const float* Bt,
 // BWD = false: out = Wl . in (+ bl on the bias column), written as T (and optionally fp32)
 // BWD = true : out = Wl^T . in, fp32, optionally accumulated
 template <typename T, int HD, bool BWD>
-__global__ __launch_bounds__(256) void fold_w_kernel(const float* __restrict__ win, const float* __restrict__ bin,
-                                                     const float* __restrict__ wl, const float* __restrict__ bl,
-                                                     T* __restrict__ wout, float* __restrict__ wout_f32,
-                                                     float* __restrict__ bout, int D, int H, int accumulate) {
-  __shared__ __attribute__((aligned(16))) float sAt[HD * HD];
-  __shared__ __attribute__((aligned(16))) float sBt[HD * FOLD_TC];
+__device__ __forceinline__ void fold_w_body(const float* __restrict__ win, const float* __restrict__ bin,
+                                            const float* __restrict__ wl, const float* __restrict__ bl,
+                                            T* __restrict__ wout, float* __restrict__ wout_f32,
+                                            float* __restrict__ bout, int D, int H, int accumulate, int bx, int by,
+                                            float* smem) {
+  float* sAt = smem;                       // [HD * HD]
+  float* sBt = smem + HD * HD;             // [HD * FOLD_TC]
   const int tc = threadIdx.x & 63, tg = threadIdx.x >> 6;
   auto put = [&](long r, int c, float v) {
     if (c < D) {
@@ -940,29 +941,29 @@ __global__ __launch_bounds__(256) void fold_w_kernel(const float* __restrict__ w
       bout[r] = (BWD && accumulate) ? bout[r] + v : v;
     }
   };
-  if ((int)blockIdx.y >= 2 * H) {                      // q part: copy / cast, HD rows per block
-    const int c = blockIdx.x * FOLD_TC + tc;
+  if (by >= 2 * H) {                      // q part: copy / cast, HD rows per block
+    const int c = bx * FOLD_TC + tc;
     if (c > D) return;
-    const int rb = ((int)blockIdx.y - 2 * H) * HD;
+    const int rb = (by - 2 * H) * HD;
 #pragma unroll 4
     for (int r = rb + tg; r < rb + HD && r < D; r += 4) put(r, c, (c < D) ? win[(long)r * D + c] : bin[r]);
     return;
   }
-  const long base = (long)D + (long)blockIdx.y * HD;   // first row of this (s,h) block
+  const long base = (long)D + (long)by * HD;   // first row of this (s,h) block
   // At[k][r]: forward needs Wl[r][k] (transpose while staging), backward Wl[k][r] (as stored)
   for (int i = threadIdx.x; i < HD * HD; i += 256) {
     const int k = i / HD, r = i % HD;
     sAt[i] = BWD ? wl[k * HD + r] : wl[r * HD + k];
   }
   for (int k = tg; k < HD; k += 4) {
-    const int c = blockIdx.x * FOLD_TC + tc;
+    const int c = bx * FOLD_TC + tc;
     sBt[k * FOLD_TC + tc] = (c < D) ? win[(base + k) * D + c] : (c == D ? bin[base + k] : 0.f);
   }
   __syncthreads();
   float acc[HD / 16][4];
   fold_tile_gemm<HD>(sAt, sBt, acc);
   constexpr int TR = HD / 16;
-  const int r0 = TR * (threadIdx.x >> 4), c0 = blockIdx.x * FOLD_TC + 4 * (threadIdx.x & 15);
+  const int r0 = TR * (threadIdx.x >> 4), c0 = bx * FOLD_TC + 4 * (threadIdx.x & 15);
 #pragma unroll
   for (int i = 0; i < TR; ++i)
 #pragma unroll
@@ -973,23 +974,31 @@ __global__ __launch_bounds__(256) void fold_w_kernel(const float* __restrict__ w
     }
 }
 
+template <typename T, int HD, bool BWD>
+__global__ __launch_bounds__(256) void fold_w_kernel(const float* __restrict__ win, const float* __restrict__ bin,
+                                                     const float* __restrict__ wl, const float* __restrict__ bl,
+                                                     T* __restrict__ wout, float* __restrict__ wout_f32,
+                                                     float* __restrict__ bout, int D, int H, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float smem[HD * HD + HD * FOLD_TC];
+  fold_w_body<T, HD, BWD>(win, bin, wl, bl, wout, wout_f32, bout, D, H, accumulate, blockIdx.x, blockIdx.y, smem);
+}
+
 // dWl[i][j] += sum_c dWeff_z[i][c] Wqkv_z[j][c] + dbeff_z[i] bqkv_z[j];  dbl[i] += dbeff_z[i].
 // grid (2H): one workgroup per (s,h) block z walks the D+1 columns in tiles of 64 (register-blocked
 // [HD x HD] accumulator) and adds its partial with fp32 atomics (2H-way contention only).
 template <int HD>
-__global__ __launch_bounds__(256) void fold_bwd_l_kernel(const float* __restrict__ dweff,
-                                                         const float* __restrict__ dbeff,
-                                                         const float* __restrict__ wqkv,
-                                                         const float* __restrict__ bqkv, float* __restrict__ dwl,
-                                                         float* __restrict__ dbl, int D) {
+__device__ __forceinline__ void fold_bwd_l_body(const float* __restrict__ dweff, const float* __restrict__ dbeff,
+                                                const float* __restrict__ wqkv, const float* __restrict__ bqkv,
+                                                float* __restrict__ dwl, float* __restrict__ dbl, int D, int bx, int by,
+                                                float* smem) {
   constexpr int TR = HD / 16;                          // thread block TR x TR of the [HD x HD] output
   constexpr int LDT = HD + 1;                          // padded: transposed staging is conflict-free
-  __shared__ float sa[64 * LDT];                       // [c][i]  dWeff tile, transposed
-  __shared__ float sb[64 * LDT];                       // [c][j]  Wqkv tile, transposed
+  float* sa = smem;                                    // [64][LDT]  dWeff tile, transposed
+  float* sb = smem + 64 * LDT;                         // [64][LDT]  Wqkv tile, transposed
   const int tc = threadIdx.x & 63, tg = threadIdx.x >> 6;
-  const long base = (long)D + (long)blockIdx.x * HD;
+  const long base = (long)D + (long)bx * HD;
   const int i0 = TR * (threadIdx.x >> 4), j0 = TR * (threadIdx.x & 15);
-  const int c = blockIdx.y * 64 + tc;                  // column D = bias column
+  const int c = by * 64 + tc;                  // column D = bias column
   float va[HD / 4], vb[HD / 4];
 #pragma unroll
   for (int q = 0; q < HD / 4; ++q) {
@@ -1022,7 +1031,50 @@ __global__ __launch_bounds__(256) void fold_bwd_l_kernel(const float* __restrict
   for (int i = 0; i < TR; ++i)
 #pragma unroll
     for (int j = 0; j < TR; ++j) atomicAdd(dwl + (long)(i0 + i) * HD + j0 + j, acc[i][j]);
-  if (blockIdx.y == 0 && threadIdx.x < HD) atomicAdd(dbl + threadIdx.x, dbeff[base + threadIdx.x]);
+  if (by == 0 && threadIdx.x < HD) atomicAdd(dbl + threadIdx.x, dbeff[base + threadIdx.x]);
+}
+
+// The whole backward of the fold in ONE launch (these kernels are a few workgroups each and purely
+// latency-bound): blocks [0, nw) map the folded weight gradient back onto qkv.{weight,bias}
+// (Wl^T . dWeff), the remaining blocks accumulate the latent_proj gradient.
+template <int HD>
+__global__ __launch_bounds__(256) void fold_bwd_all_kernel(const float* __restrict__ dweff,
+                                                           const float* __restrict__ dbeff,
+                                                           const float* __restrict__ wqkv,
+                                                           const float* __restrict__ bqkv,
+                                                           const float* __restrict__ wl, float* __restrict__ dwqkv,
+                                                           float* __restrict__ dbqkv, float* __restrict__ dwl,
+                                                           float* __restrict__ dbl, int D, int H, int accumulate,
+                                                           int gwx, int nw, int glx) {
+  constexpr int SW = HD * HD + HD * FOLD_TC, SL = 2 * 64 * (HD + 1);
+  __shared__ __attribute__((aligned(16))) float smem[SW > SL ? SW : SL];
+  const int b = blockIdx.x;
+  if (b < nw) {
+    fold_w_body<float, HD, true>(dweff, dbeff, wl, nullptr, dwqkv, nullptr, dbqkv, D, H, accumulate, b % gwx, b / gwx, smem);
+  } else {
+    const int r = b - nw;
+    fold_bwd_l_body<HD>(dweff, dbeff, wqkv, bqkv, dwl, dbl, D, r % glx, r / glx, smem);
+  }
+}
+
+// Forward folds of up to FOLD_MAX independent blocks (the layers of one encoder) in ONE launch:
+// the fold only depends on parameters, so all of them can run before the first block.
+constexpr int FOLD_MAX = 32;
+struct FoldBatch {
+  const float* wqkv[FOLD_MAX];
+  const float* bqkv[FOLD_MAX];
+  const float* wl[FOLD_MAX];
+  const float* bl[FOLD_MAX];
+  void* weff[FOLD_MAX];
+  float* beff[FOLD_MAX];
+};
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void fold_w_multi_kernel(FoldBatch fb, int D, int H) {
+  __shared__ __attribute__((aligned(16))) float smem[HD * HD + HD * FOLD_TC];
+  const int z = blockIdx.z;
+  fold_w_body<T, HD, false>(fb.wqkv[z], fb.bqkv[z], fb.wl[z], fb.bl[z], reinterpret_cast<T*>(fb.weff[z]), nullptr,
+                            fb.beff[z], D, H, 0, blockIdx.x, blockIdx.y, smem);
 }
 
 template <typename T, bool BWD>
@@ -1168,6 +1220,35 @@ extern "C" int favit_mhla_fold_fwd(const float* wqkv, const float* bqkv, const f
   return FAVIT_ERR_INVALID;
 }
 
+extern "C" int favit_mhla_fold_fwd_multi(int32_t n, const float* const* wqkv, const float* const* bqkv,
+                                         const float* const* wl, const float* const* bl, void* const* weff,
+                                         int weff_dtype, float* const* beff, int32_t D, int32_t H, void* stream) {
+  if (n <= 0 || n > FOLD_MAX || !wqkv || !bqkv || !wl || !bl || !weff || !beff || D <= 0 || H <= 0 || D % H)
+    return FAVIT_ERR_INVALID;
+  FoldBatch fb;
+  for (int i = 0; i < n; ++i) {
+    if (!wqkv[i] || !bqkv[i] || !wl[i] || !bl[i] || !weff[i] || !beff[i]) return FAVIT_ERR_INVALID;
+    fb.wqkv[i] = wqkv[i]; fb.bqkv[i] = bqkv[i]; fb.wl[i] = wl[i]; fb.bl[i] = bl[i];
+    fb.weff[i] = weff[i]; fb.beff[i] = beff[i];
+  }
+  const int hd = D / H;
+  const dim3 grid((D + 1 + FOLD_TC - 1) / FOLD_TC, 2 * H + (D + hd - 1) / hd, n);
+  hipStream_t st = as_stream(stream);
+#define FAVIT_FOLD_MULTI(T)                                                                                   \
+  switch (hd) {                                                                                               \
+    case 16: hipLaunchKernelGGL((fold_w_multi_kernel<T, 16>), grid, dim3(256), 0, st, fb, D, H); break;       \
+    case 32: hipLaunchKernelGGL((fold_w_multi_kernel<T, 32>), grid, dim3(256), 0, st, fb, D, H); break;       \
+    case 64: hipLaunchKernelGGL((fold_w_multi_kernel<T, 64>), grid, dim3(256), 0, st, fb, D, H); break;       \
+    default: return FAVIT_ERR_UNSUPPORTED;                                                                    \
+  }
+  if (weff_dtype == FAVIT_F32) { FAVIT_FOLD_MULTI(float) }
+  else if (weff_dtype == FAVIT_BF16) { FAVIT_FOLD_MULTI(bf16_t) }
+  else return FAVIT_ERR_INVALID;
+#undef FAVIT_FOLD_MULTI
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
 extern "C" int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const float* wqkv, const float* bqkv,
                                    const float* wl, float* dwqkv, float* dbqkv, float* dwl, float* dbl, int32_t D,
                                    int32_t H, int32_t accumulate, void* stream) {
@@ -1175,16 +1256,18 @@ extern "C" int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const
     return FAVIT_ERR_INVALID;
   const int hd = D / H;
   hipStream_t st = as_stream(stream);
-  const int rc = launch_fold_w<float, true>(dweff, dbeff, wl, nullptr, dwqkv, nullptr, dbqkv, D, H, accumulate, st);
-  if (rc != FAVIT_OK) return rc;
   if (!accumulate) {
     (void)hipMemsetAsync(dwl, 0, sizeof(float) * hd * hd, st);
     (void)hipMemsetAsync(dbl, 0, sizeof(float) * hd, st);
   }
+  const int gwx = (D + 1 + FOLD_TC - 1) / FOLD_TC, gwy = 2 * H + (D + hd - 1) / hd;      // fold_w grid
+  const int glx = 2 * H, gly = (D + 64) / 64;                                             // fold_bwd_l grid
+  const int nw = gwx * gwy;
+  const dim3 grid((unsigned)(nw + glx * gly));
   switch (hd) {
-    case 16: hipLaunchKernelGGL(fold_bwd_l_kernel<16>, dim3(2 * H, (D + 64) / 64), dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
-    case 32: hipLaunchKernelGGL(fold_bwd_l_kernel<32>, dim3(2 * H, (D + 64) / 64), dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
-    case 64: hipLaunchKernelGGL(fold_bwd_l_kernel<64>, dim3(2 * H, (D + 64) / 64), dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, dwl, dbl, D); break;
+    case 16: hipLaunchKernelGGL(fold_bwd_all_kernel<16>, grid, dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, wl, dwqkv, dbqkv, dwl, dbl, D, H, accumulate, gwx, nw, glx); break;
+    case 32: hipLaunchKernelGGL(fold_bwd_all_kernel<32>, grid, dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, wl, dwqkv, dbqkv, dwl, dbl, D, H, accumulate, gwx, nw, glx); break;
+    case 64: hipLaunchKernelGGL(fold_bwd_all_kernel<64>, grid, dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, wl, dwqkv, dbqkv, dwl, dbl, D, H, accumulate, gwx, nw, glx); break;
     default: return FAVIT_ERR_UNSUPPORTED;
   }
   FAVIT_CHECK_LAUNCH();

@@ -418,7 +418,7 @@ class MHLAChain:
             raise ValueError("window_size must be odd: the reference crashes on even sizes (models/mhla.py:83)")
         self.H, self.W, self.p_attn, self.p_proj = H, W, p_attn, p_proj
 
-    def fwd(self, xn, prm, B, L, residual, mask, training):
+    def fwd(self, xn, prm, B, L, residual, mask, training, pre=None):
         wqkv, bqkv, wl, bl, wp, bp = prm
         M, D = xn.shape
         H, hd = self.H, D // self.H
@@ -426,7 +426,7 @@ class MHLAChain:
         pp = self.p_proj if training else 0.0
         sa = _seed() if pa > 0 else 0
         sp = _seed() if pp > 0 else 0
-        weff, beff = K.mhla_fold_fwd(wqkv, bqkv, wl, bl, H, xn.dtype)
+        weff, beff = pre if pre is not None else K.mhla_fold_fwd(wqkv, bqkv, wl, bl, H, xn.dtype)
         qkv = lin_fwd(xn, weff, beff, M, 3 * D, D, xn.dtype)
         o = K.mhla_attn_fwd(qkv, B, L, H, hd, self.W, mask, pa, sa)
         wp_c = wcast(wp)
@@ -716,8 +716,19 @@ class EncoderOp:
         cdt = get_compute_dtype()
         x = _as_f32(x).reshape(M, D)
         tapes = []
+        # the latent_proj folds only depend on parameters: all MHLA blocks of equal geometry in ONE launch
+        pre = [None] * len(self.blocks)
+        idx, fp, off = [], [], 0
+        for bi, bs in enumerate(self.blocks):
+            if isinstance(bs.attn, MHLAChain):
+                idx.append(bi)
+                fp.append(tuple(prm[off + 2:off + 6]))
+            off += bs.n
+        if 2 <= len(idx) <= 32 and len({(self.blocks[i].attn.H, tuple(q[0].shape)) for i, q in zip(idx, fp)}) == 1:
+            for bi, we in zip(idx, K.mhla_fold_fwd_multi(fp, self.blocks[idx[0]].attn.H, cdt)):
+                pre[bi] = we
         off = 0
-        for bs in self.blocks:
+        for bi, bs in enumerate(self.blocks):
             p = list(prm[off:off + bs.n])
             off += bs.n
             na = len(bs.attn.names)
@@ -726,7 +737,10 @@ class EncoderOp:
             g2, b2 = p[2 + na], p[3 + na]
             pm = p[4 + na:]
             xn1, mu1, rs1 = K.layernorm_fwd(x, D, g1, b1, M, D, cdt)
-            x1, sa = bs.attn.fwd(xn1, pa, B, L, x, self.mask, self.training)
+            if pre[bi] is not None:
+                x1, sa = bs.attn.fwd(xn1, pa, B, L, x, self.mask, self.training, pre=pre[bi])
+            else:
+                x1, sa = bs.attn.fwd(xn1, pa, B, L, x, self.mask, self.training)
             xn2, mu2, rs2 = K.layernorm_fwd(x1, D, g2, b2, M, D, cdt)
             x2, sm = bs.mlp.fwd(xn2, pm, x1, self.training)
             tapes.append((x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm))

@@ -233,6 +233,24 @@ def mhla_fold_fwd(wqkv, bqkv, wl, bl, H, dtype):
     return weff, beff
 
 
+def mhla_fold_fwd_multi(params, H, dtype):
+    """params: list of (wqkv, bqkv, wl, bl) per block -> list of (weff, beff); one launch for all blocks."""
+    n = len(params)
+    D = params[0][0].shape[1]
+    dev = params[0][0].device
+    for q in params:
+        require_gpu(*q)
+    weff = torch.empty((n, 3 * D, D), dtype=dtype, device=dev)
+    beff = torch.empty((n, 3 * D), dtype=torch.float32, device=dev)
+    arr = C.c_void_p * n
+    cols = [arr(*[q[j].data_ptr() for q in params]) for j in range(4)]
+    wp = arr(*[weff[i].data_ptr() for i in range(n)])
+    bp = arr(*[beff[i].data_ptr() for i in range(n)])
+    _abi.check(_abi.lib().favit_mhla_fold_fwd_multi(n, cols[0], cols[1], cols[2], cols[3], wp, dt(weff), bp, D, H, _st()),
+               "favit_mhla_fold_fwd_multi")
+    return [(weff[i], beff[i]) for i in range(n)]
+
+
 def mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H, out=None):
     """out = (dwqkv, dbqkv, dwl, dbl) gradient buffers to ACCUMULATE into, or None for fresh tensors."""
     D = wqkv.shape[1]

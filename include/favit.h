@@ -159,6 +159,12 @@ int favit_mhla_fold_fwd(const float* wqkv, const float* bqkv, const float* wl, c
                         int weff_dtype, float* weff_f32 /* optional fp32 copy */, float* beff, int32_t D,
                         int32_t H, void* stream);
 /* accumulate=1: the four outputs are added to (gradient buffers), else overwritten */
+/* The forward fold of n (<= 32) independent blocks -- e.g. every layer of an encoder -- in ONE launch.
+ * The arguments are HOST arrays of n device pointers; weff[i] / beff[i] as in favit_mhla_fold_fwd. */
+int favit_mhla_fold_fwd_multi(int32_t n, const float* const* wqkv, const float* const* bqkv, const float* const* wl,
+                              const float* const* bl, void* const* weff, int weff_dtype, float* const* beff,
+                              int32_t D, int32_t H, void* stream);
+
 int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const float* wqkv, const float* bqkv,
                         const float* wl, float* dwqkv, float* dbqkv, float* dwl, float* dbl, int32_t D, int32_t H,
                         int32_t accumulate, void* stream);
