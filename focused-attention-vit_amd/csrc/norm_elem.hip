@@ -220,6 +220,38 @@ __global__ void patchify_fwd_kernel(const float* __restrict__ img, T* __restrict
   }
 }
 
+// Strip version: one workgroup owns the P image rows of one (image, patch-row) -- C x P x HW elements.
+// It reads them with coalesced 16-byte loads into LDS (already converted to T) and writes the g patches
+// of the strip, K = P*P*C contiguous elements each, with 16-byte stores; the (p1 p2 c) shuffle happens
+// between LDS and registers.  Needs HW % 4 == 0 and K % VW == 0 (VW = elements per 16 bytes).
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_fwd_strip_kernel(const float* __restrict__ img, T* __restrict__ out, int B,
+                                                                 int C, int HW, int P) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* s = reinterpret_cast<T*>(smem_raw);                  // [C][P][HW]
+  constexpr int VW = 16 / (int)sizeof(T);
+  const int g = HW / P, ph = blockIdx.x % g, b = blockIdx.x / g;
+  const int rowq = HW / 4, nq = C * P * rowq;             // float4 quads of the strip
+  for (int q = threadIdx.x; q < nq; q += 256) {
+    const int x4 = q % rowq, r = q / rowq, p1 = r % P, c = r / P;
+    const float4 v = *reinterpret_cast<const float4*>(img + (((long)b * C + c) * HW + (ph * P + p1)) * HW + 4 * x4);
+    T* d = s + (c * P + p1) * HW + 4 * x4;
+    d[0] = from_f32<T>(v.x); d[1] = from_f32<T>(v.y); d[2] = from_f32<T>(v.z); d[3] = from_f32<T>(v.w);
+  }
+  __syncthreads();
+  const int K = P * P * C, nv = g * K / VW;
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    const int e0 = (i * VW) % K, pw = (i * VW) / K;
+    T v[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      const int e = e0 + j, c = e % C, pp = e / C, p2 = pp % P, p1 = pp / P;
+      v[j] = s[(c * P + p1) * HW + pw * P + p2];
+    }
+    *reinterpret_cast<uint4*>(out + ((long)b * g * g + ph * g + pw) * K + e0) = *reinterpret_cast<const uint4*>(v);
+  }
+}
+
 __global__ void patchify_bwd_kernel(const float* __restrict__ dpatch, float* __restrict__ dimg, int B, int C, int HW,
                                     int P) {
   const int g = HW / P;
@@ -268,6 +300,44 @@ __global__ void embed_prologue_bwd_kernel(const float* __restrict__ dx, T* __res
     }
     if (dpos) dpos[i] = s;
     if (l == 0 && dcls) dcls[d] = s;
+  }
+}
+
+// Chunked version: grid.y splits the batch; every thread owns one float4 of a token row position (l, d4),
+// walks its chunk of images with 16-byte loads / stores and adds its partial sums with fp32 atomics
+// (dcls / dpos are zeroed by the caller of this kernel).  Needs D % 4 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_prologue_bwd_chunk_kernel(const float* __restrict__ dx, T* __restrict__ dtok,
+                                                                       float* __restrict__ dcls, float* __restrict__ dpos,
+                                                                       int B, int N, int D, int bchunk) {
+  const int d4n = D >> 2;
+  const long nq = (long)(N + 1) * d4n;
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const int l = (int)(q / d4n), d = 4 * (int)(q % d4n);
+  const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+  const long LD = (long)(N + 1) * D;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = b0; b < b1; ++b) {
+    const float4 v = *reinterpret_cast<const float4*>(dx + (long)b * LD + (long)l * D + d);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    if (l > 0 && dtok) {
+      T* o = dtok + ((long)b * N + (l - 1)) * D + d;
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(o) = v;
+      } else {
+        bf16x4 t;
+        t[0] = (bf16_t)v.x; t[1] = (bf16_t)v.y; t[2] = (bf16_t)v.z; t[3] = (bf16_t)v.w;
+        *reinterpret_cast<bf16x4*>(o) = t;
+      }
+    }
+  }
+  if (dpos) {
+    float* p = dpos + (long)l * D + d;
+    atomicAdd(p, s.x); atomicAdd(p + 1, s.y); atomicAdd(p + 2, s.z); atomicAdd(p + 3, s.w);
+  }
+  if (l == 0 && dcls) {
+    atomicAdd(dcls + d, s.x); atomicAdd(dcls + d + 1, s.y); atomicAdd(dcls + d + 2, s.z); atomicAdd(dcls + d + 3, s.w);
   }
 }
 
@@ -434,6 +504,21 @@ extern "C" int favit_patchify_fwd(const float* img, void* out, int out_dtype, in
   if (!img || !out || B <= 0 || C <= 0 || HW <= 0 || P <= 0 || HW % P) return FAVIT_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   const long total = (long)B * C * HW * HW;
+  {
+    const int esz = out_dtype == FAVIT_F32 ? 4 : 2, vw = 16 / esz;
+    const size_t lds = (size_t)C * P * HW * esz;
+    const long Kp = (long)P * P * C;
+    if ((out_dtype == FAVIT_F32 || out_dtype == FAVIT_BF16) && (HW % 4) == 0 && (Kp % vw) == 0 && lds <= 64 * 1024 &&
+        (reinterpret_cast<uintptr_t>(img) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+      const dim3 grid((unsigned)(B * (HW / P)));
+      if (out_dtype == FAVIT_F32)
+        hipLaunchKernelGGL((patchify_fwd_strip_kernel<float>), grid, dim3(256), lds, st, img, (float*)out, B, C, HW, P);
+      else
+        hipLaunchKernelGGL((patchify_fwd_strip_kernel<bf16_t>), grid, dim3(256), lds, st, img, (bf16_t*)out, B, C, HW, P);
+      FAVIT_CHECK_LAUNCH();
+      return FAVIT_OK;
+    }
+  }
   if (out_dtype == FAVIT_F32)
     hipLaunchKernelGGL((patchify_fwd_kernel<float>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, img, (float*)out, B, C, HW, P);
   else if (out_dtype == FAVIT_BF16)
@@ -468,6 +553,21 @@ extern "C" int favit_embed_prologue_bwd(const float* dx, void* dtok, int dtok_dt
   if (!dx || B <= 0 || N <= 0 || D <= 0) return FAVIT_ERR_INVALID;
   const long total = (long)(N + 1) * D;
   hipStream_t st = as_stream(stream);
+  if ((D & 3) == 0 && B >= 32 && (dtok_dtype == FAVIT_F32 || dtok_dtype == FAVIT_BF16) &&
+      (reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (!dtok || (reinterpret_cast<uintptr_t>(dtok) & 15) == 0)) {
+    // large batches: split the batch over grid.y (the one-thread-per-element kernel below walks all B
+    // images serially with 4-byte accesses: 119 us at B = 256, L = 197, D = 384)
+    if (dpos) (void)hipMemsetAsync(dpos, 0, sizeof(float) * total, st);
+    if (dcls) (void)hipMemsetAsync(dcls, 0, sizeof(float) * D, st);
+    const int chunks = B >= 128 ? 16 : 4, bchunk = (B + chunks - 1) / chunks;
+    const dim3 grid((unsigned)((total / 4 + 255) / 256), (unsigned)chunks);
+    if (dtok_dtype == FAVIT_F32)
+      hipLaunchKernelGGL((embed_prologue_bwd_chunk_kernel<float>), grid, dim3(256), 0, st, dx, (float*)dtok, dcls, dpos, B, N, D, bchunk);
+    else
+      hipLaunchKernelGGL((embed_prologue_bwd_chunk_kernel<bf16_t>), grid, dim3(256), 0, st, dx, (bf16_t*)dtok, dcls, dpos, B, N, D, bchunk);
+    FAVIT_CHECK_LAUNCH();
+    return FAVIT_OK;
+  }
   if (dtok_dtype == FAVIT_F32)
     hipLaunchKernelGGL((embed_prologue_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, st, dx, (float*)dtok, dcls, dpos, B, N, D);
   else if (dtok_dtype == FAVIT_BF16)

@@ -154,28 +154,39 @@ def test_cast_roundtrip(K):
     assert torch.equal(K.cast(b, torch.float32), b.float())
 
 
-def test_patchify_matches_einops_order(K):
+@pytest.mark.parametrize("B,C,HW,P", [(2, 3, 32, 4), (3, 3, 224, 16), (2, 1, 30, 5), (2, 3, 36, 6), (1, 3, 384, 16)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_patchify_matches_einops_order(K, B, C, HW, P, dtype):
+    """Both patchify kernels (LDS strip with 16-byte accesses; element-wise fallback for odd sizes) against the
+    reference's einops order 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)' -- a pure permutation: bit-exact."""
     from oracle import favit_oracle as O
-    x = torch.randn(2, 3, 32, 32, device=DEV)
-    p = K.patchify_fwd(x, 4, torch.float32)
-    assert torch.equal(p.cpu(), O.patch_rearrange(x.cpu(), 4).reshape(-1, 48))
-    d = torch.randn_like(p)
-    back = K.patchify_bwd(d, 2, 3, 32, 4)
-    xr = x.cpu().clone().requires_grad_(True)
-    (O.patch_rearrange(xr, 4).reshape(-1, 48) * d.cpu()).sum().backward()
-    assert torch.equal(back.cpu(), xr.grad)
+    g = torch.Generator(device=DEV).manual_seed(HW + P)
+    x = torch.randn(B, C, HW, HW, device=DEV, generator=g)
+    Kp = P * P * C
+    p = K.patchify_fwd(x, P, dtype)
+    ref = O.patch_rearrange(x.cpu(), P).reshape(-1, Kp)
+    assert torch.equal(p.cpu(), ref.to(dtype))
+    if dtype == torch.float32:
+        d = torch.randn_like(p)
+        back = K.patchify_bwd(d, B, C, HW, P)
+        xr = x.cpu().clone().requires_grad_(True)
+        (O.patch_rearrange(xr, P).reshape(-1, Kp) * d.cpu()).sum().backward()
+        assert torch.equal(back.cpu(), xr.grad)
 
 
-def test_embed_prologue(K):
-    B, N, D = 3, 16, 64
-    tok, cls, pos = torch.randn(B, N, D, device=DEV), torch.randn(D, device=DEV), torch.randn(N + 1, D, device=DEV)
+@pytest.mark.parametrize("B,N,D", [(3, 16, 64), (64, 16, 64), (256, 196, 384), (40, 7, 20)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_prologue(K, B, N, D, dtype):
+    g = torch.Generator(device=DEV).manual_seed(B + N)
+    tok = torch.randn(B, N, D, device=DEV, generator=g)
+    cls, pos = torch.randn(D, device=DEV, generator=g), torch.randn(N + 1, D, device=DEV, generator=g)
     x = K.embed_prologue_fwd(tok, cls, pos, B, N, D)
     ref = torch.cat([cls.expand(B, 1, D), tok], 1) + pos
     assert torch.equal(x, ref)
-    dx = torch.randn_like(x)
-    dtok, dcls, dpos = K.embed_prologue_bwd(dx, B, N, D, torch.float32)
-    assert torch.equal(dtok.reshape(B, N, D), dx[:, 1:])
-    assert rel_l2(dcls, dx[:, 0].sum(0)) < 1e-6 and rel_l2(dpos, dx.sum(0)) < 1e-6
+    dx = torch.randn(B, N + 1, D, device=DEV, generator=g)
+    dtok, dcls, dpos = K.embed_prologue_bwd(dx, B, N, D, dtype)
+    assert torch.equal(dtok.reshape(B, N, D), dx[:, 1:].to(dtype))
+    assert rel_l2(dcls, dx[:, 0].double().sum(0)) < 1e-6 and rel_l2(dpos, dx.double().sum(0)) < 1e-6
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
