@@ -1032,6 +1032,107 @@ int launch_p7(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
   return FAVIT_OK;
 }
 
+// --------------------------------------------------------------------------------------
+// bf16 kernel "s64": 64x128 tile, 4 waves (2x2, 32x64 each), BK = 64, three 24-KiB stages, for problems
+// that give the 128x128 kernels fewer than one workgroup per CU (the 17-token SPPP configurations,
+// ViT-Tiny, heads): twice the workgroups, a three-deep DMA ring instead of the double buffer, and the
+// barrier-free wave-private epilogue.  A is k-major; B either layout.  Such launches are latency-bound
+// (6 K-steps at K = 384), so what counts is the length of one workgroup's dependency chain.
+// (The opposite choice -- the 256x128 kernel on these problems -- measured 4.68 -> 5.44 ms per SPPP step.)
+// --------------------------------------------------------------------------------------
+constexpr int S64_BM = 64;
+constexpr int S64_A_BYTES = 64 * 128;                    // 8 KiB
+constexpr int S64_STAGE = S64_A_BYTES + OP16_BYTES;      // 24 KiB
+constexpr int S64_LDS = 3 * S64_STAGE;                   // 73728
+
+template <bool BKM, typename OutT>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_s64_kernel(KParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = blockIdx.z;
+  const long m0 = (long)(tile / p.tiles_n) * S64_BM;
+  const long n0 = (long)(tile % p.tiles_n) * BN;
+  const long zo = z / p.batch_inner, zi = z % p.batch_inner;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + zo * p.sAo + zi * p.sAi;
+  const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B) + zo * p.sBo + zi * p.sBi;
+  OutT* C = reinterpret_cast<OutT*>(p.C) + zo * p.sCo + zi * p.sCi;
+  const int nk = (int)(p.K / BK16);
+
+  f32x4 acc[4][4];                        // rows 0..31 of the wave tile live in acc[0..1][*]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // 6 one-KiB pieces per wave and stage: 2 of A (8 pieces = 64 rows), 4 of B (16 pieces)
+  const bf16_t* sa[2];
+  const bf16_t* sb[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) sa[j] = glds_src<true>(A, p.lda, m0, p.M, 0, wave * 2 + j, lane);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sb[j] = glds_src<BKM>(Bm, p.ldb, n0, p.N, 0, wave * 4 + j, lane);
+  auto issue = [&](int buf) {
+    char* st = smem + buf * S64_STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + (wave * 2 + j) * 1024), 16, 0, 0);
+      sa[j] += BK16;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sb[j], (lptr_t)(st + S64_A_BYTES + (wave * 4 + j) * 1024), 16, 0, 0);
+      sb[j] += BKM ? BK16 : BK16 * p.ldb;
+    }
+  };
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);
+    const char* la = smem + cur * S64_STAGE;
+    const char* lb = la + S64_A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[2], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = load_frag16<true>(la, wr * 32 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = load_frag16<BKM>(lb, wc * 64 + j * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
+  wave_epilogue_rows<bf16_t, OutT, 0, 2>(p, acc, C, m0 + wr * 32, n0 + wc * 64, lane,
+                                         reinterpret_cast<float*>(smem + wave * WEPI_BYTES), true, p.alpha);
+}
+
+template <typename Kn>
+int launch_s64(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
+  static const void* seen[8];
+  static int nseen = 0;
+  const void* kptr = reinterpret_cast<const void*>(kernel);
+  bool known = false;
+  for (int i = 0; i < nseen; ++i) known = known || seen[i] == kptr;
+  if (!known) {
+    (void)hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, S64_LDS);
+    if (nseen < 8) seen[nseen++] = kptr;
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(NTHREADS), S64_LDS, st, kp);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
 // Grouped weight-gradient launch: several dW = dY^T.X problems that share the token dimension (the
 // four Linear layers of one transformer block) run as ONE grid.  Their tiles together fill the 64
 // workgroup slots of an XCD with a single K-split per XCD (8 splits in all instead of 24 each), which
@@ -1439,6 +1540,20 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
         default: return launch_p4(gemm_bf16_p4_kernel<false, false, float>, kp, grid4, st);
       }
     }
+  }
+  // fewer 128x128 tiles than 1.5 per CU: 64-row tiles, three-deep DMA ring (latency-bound launches)
+  if (glds_ok && !force128 && getenv("FAVIT_GEMM_NO_S64") == nullptr && splits == 1 && !atomic && g->a_kmajor &&
+      !g->a_rowsum && tiles < 384 && g->M > 64 && g->K >= 2 * BK16) {
+    KParams ks = kp;
+    const long tm = (g->M + S64_BM - 1) / S64_BM;
+    ks.ntiles = (int)(tm * tiles_n);
+    dim3 grids((unsigned)(tm * tiles_n), 1u, (unsigned)batch);
+    if (g->out_dtype == FAVIT_BF16) {
+      if (g->b_kmajor) return launch_s64(gemm_bf16_s64_kernel<true, bf16_t>, ks, grids, st);
+      return launch_s64(gemm_bf16_s64_kernel<false, bf16_t>, ks, grids, st);
+    }
+    if (g->b_kmajor) return launch_s64(gemm_bf16_s64_kernel<true, float>, ks, grids, st);
+    return launch_s64(gemm_bf16_s64_kernel<false, float>, ks, grids, st);
   }
   if (glds_ok) {
     if (g->out_dtype == FAVIT_BF16) {
