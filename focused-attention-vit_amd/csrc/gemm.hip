@@ -1360,6 +1360,25 @@ int launch(K kernel, const KParams& kp, dim3 grid, hipStream_t st) {
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// Experiment switches (tools/README.md), read once per process.
+struct GemmKnobs {
+  int dbg, store_policy;
+  bool force128, no_p4, no_p7, no_s64;
+  GemmKnobs() {
+    const char* e;
+    dbg = (e = getenv("FAVIT_GEMM_DBG")) ? atoi(e) : 0;
+    store_policy = (e = getenv("FAVIT_GEMM_STORE")) ? atoi(e) : 1;
+    force128 = getenv("FAVIT_GEMM_TILE128") != nullptr;
+    no_p4 = getenv("FAVIT_GEMM_NO_P4") != nullptr;
+    no_p7 = getenv("FAVIT_GEMM_NO_P7") != nullptr;
+    no_s64 = getenv("FAVIT_GEMM_NO_S64") != nullptr;
+  }
+};
+static const GemmKnobs& knobs() {
+  static const GemmKnobs k;
+  return k;
+}
+
 }  // namespace
 
 extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
@@ -1445,10 +1464,10 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.alpha = g->alpha;
   kp.scale_a = fp8 ? g->scale_a : nullptr;
   kp.scale_b = fp8 ? g->scale_b : nullptr;
-  { const char* e = getenv("FAVIT_GEMM_DBG"); kp.dbg = e ? atoi(e) : 0; }
+  kp.dbg = knobs().dbg;
   // epilogue outputs / residual / aux reads are touched once: non-temporal keeps them from evicting
   // the operand panels the co-resident workgroups share in L2 (fc2: 140 -> 114 us)
-  { const char* e = getenv("FAVIT_GEMM_STORE"); kp.store_policy = e ? atoi(e) : 1; }
+  kp.store_policy = knobs().store_policy;
   if (g->dropout_p < 0.f || g->dropout_p >= 1.f) return FAVIT_ERR_INVALID;
   kp.drop_thresh = dropout_threshold(g->dropout_p);
   kp.drop_scale = 1.0f / (1.0f - g->dropout_p);
@@ -1501,12 +1520,12 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   const bool glds_ok = g->in_dtype == FAVIT_BF16 && kp.a_vec && kp.b_vec && (g->K % BK16) == 0 && g->K > 0 &&
                        (g->a_kmajor || g->M >= 8) && (g->b_kmajor || g->N >= 8) &&
                        (g->a_kmajor || (g->M % 8) == 0) && (g->b_kmajor || (g->N % 8) == 0);
-  const bool force128 = getenv("FAVIT_GEMM_TILE128") != nullptr;
-  const bool no_p4 = getenv("FAVIT_GEMM_NO_P4") != nullptr;
+  const bool force128 = knobs().force128;
+  const bool no_p4 = knobs().no_p4;
   // large GEMMs: 256x128 tiles, 2 workgroups per CU, wave-private epilogue (plain or fp32-atomic)
   const long t4 = ((g->M + 255) / 256) * tiles_n;
   // 256x256 tiles: single-pass NT problems with K >= 512 and N a multiple of 256 (the D = 768 forward GEMMs)
-  const bool no_p7 = getenv("FAVIT_GEMM_NO_P7") != nullptr;
+  const bool no_p7 = knobs().no_p7;
   if (glds_ok && !force128 && !no_p4 && !no_p7 && splits == 1 && !atomic && batch == 1 && g->a_kmajor && g->b_kmajor &&
       g->M >= 1024 && (g->N % P7_BN) == 0 && (g->K % P4_BK) == 0 && g->K >= 512 &&
       ((g->M + 255) / 256) * (g->N / P7_BN) >= 256) {
@@ -1542,7 +1561,7 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
     }
   }
   // fewer 128x128 tiles than 1.5 per CU: 64-row tiles, three-deep DMA ring (latency-bound launches)
-  if (glds_ok && !force128 && getenv("FAVIT_GEMM_NO_S64") == nullptr && splits == 1 && !atomic && g->a_kmajor &&
+  if (glds_ok && !force128 && !knobs().no_s64 && splits == 1 && !atomic && g->a_kmajor &&
       !g->a_rowsum && tiles < 384 && g->M > 64 && g->K >= 2 * BK16) {
     KParams ks = kp;
     const long tm = (g->M + S64_BM - 1) / S64_BM;
