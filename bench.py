@@ -148,8 +148,8 @@ def main():
     t0 = time.perf_counter()
     traced_steps = 0
     for s in range(args.steps):
-        # HIP events around every favit_gemm launch cost ~5 % of a step: trace every 4th timed step
-        K.GEMM_TRACE = trace if (trace is not None and s % 4 == 0) else None
+        # HIP events around every favit_gemm launch cost ~5 % of a step: trace every 10th timed step
+        K.GEMM_TRACE = trace if (trace is not None and s % 10 == 0) else None
         traced_steps += int(K.GEMM_TRACE is not None)
         ev[s][0].record()
         opt.zero_grad()
