@@ -22,6 +22,7 @@
 // up with 4 consecutive n for one m: the accumulators go to LDS as float4 and the
 // epilogue (bias / GELU / dGELU / residual / atomics) runs on full coalesced rows.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -154,25 +155,70 @@ __device__ __forceinline__ void stage_store16(char* lds, const uint4 (&regs)[4],
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
-// fragment for the 16 rows starting at r0, k-substep ks (32 wide)
+// k-major fragment for the 16 rows starting at r0, k-substep ks (32 wide) of a BK = 64 image
 template <bool KMAJOR>
 __device__ __forceinline__ bf16x8 load_frag16(const char* lds, int r0, int ks, int lane) {
-  if (KMAJOR) {
-    const int row = r0 + (lane & 15);
-    const int kc = ks * 4 + (lane >> 4);
-    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+  static_assert(KMAJOR, "mn-major fragments go through load_frags4 (tr_read_pair)");
+  const int row = r0 + (lane & 15);
+  const int kc = ks * 4 + (lane >> 4);
+  return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+}
+
+// mn-major fragments without the compiler's LDS-DMA alias wait.  hipcc cannot tell that a
+// ds_read_b64_tr_b16 (an intrinsic without memory operands) does not touch the stage a global_load_lds
+// issued a moment ago is still filling, and puts `s_waitcnt vmcnt(0)` in front of the first transposed
+// read of every K-step: the prefetch it was meant to overlap is drained before any MFMA issues
+// (measured: NN 20 % slower than NT on identical shapes, 1.09 us per K-step in the weight-gradient
+// kernel).  Issued as inline asm the reads carry no such dependency; ordering against the DMA is what
+// the kernel's own counted vmcnt + barrier already establish, and their completion is waited for
+// explicitly (tr_fence: every raw register pair is an in/out operand of the s_waitcnt, so no consumer
+// can be scheduled above it).
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+__device__ __forceinline__ void tr_read_pair(const char* lds, int r0, int ks, int lane, u32x2_t& lo, u32x2_t& hi) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int krow = ks * 32 + 8 * g + q;
+  const int byte = krow * 256 + ((((r0 + 4 * p) * 2)) ^ (hsw(krow) << 5));
+  typedef __attribute__((address_space(3))) const char* lds_cptr;
+  const unsigned addr = (unsigned)(uintptr_t)(lds_cptr)(lds + byte);
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(addr) : "memory");
+}
+
+__device__ __forceinline__ void tr_fence(u32x2_t (&l)[4], u32x2_t (&h)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3])
+               :
+               : "memory");
+}
+
+__device__ __forceinline__ bf16x8 tr_pack(const u32x2_t& lo, const u32x2_t& hi) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  const u32x4_t r = {lo.x, lo.y, hi.x, hi.y};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// the 4 fragments of a 64-row operand slice (rows r0, r0+16, ...), k-substep ks of a BK = 64 or BK = 32 image
+template <bool KMAJOR, bool BK32>
+__device__ __forceinline__ void load_frags4(const char* lds, int r0, int ks, int lane, bf16x8 (&f)[4]) {
+  if constexpr (KMAJOR) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (BK32) {
+        const int row = r0 + i * 16 + (lane & 15), c = lane >> 4;
+        f[i] = *reinterpret_cast<const bf16x8*>(lds + row * 64 + ((c ^ ((-(row >> 2)) & 3)) << 4));
+      } else {
+        const int row = r0 + i * 16 + (lane & 15), kc = ks * 4 + (lane >> 4);
+        f[i] = *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+      }
+    }
   } else {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const int krow = ks * 32 + 8 * g + q;
-    const int byte = krow * 256 + ((((r0 + 4 * p) * 2)) ^ (hsw(krow) << 5));
-    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + byte));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + byte + 4 * 256));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
-    s16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return __builtin_bit_cast(bf16x8, r);
+    u32x2_t l[4], h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tr_read_pair(lds, r0 + i * 16, ks, lane, l[i], h[i]);
+    tr_fence(l, h);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = tr_pack(l[i], h[i]);
   }
 }
 
@@ -341,10 +387,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(KParams p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = load_frag16<AK>(ldsA(cur), wr * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = load_frag16<BKM>(ldsB(cur), wc * 64 + j * 16, ks, lane);
+      load_frags4<AK, false>(ldsA(cur), wr * 64, ks, lane, af);
+      load_frags4<BKM, false>(ldsB(cur), wc * 64, ks, lane, bfr);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -508,10 +552,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_glds_kernel(KParams p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = load_frag16<AK>(ldsA(cur), wr * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = load_frag16<BKM>(ldsB(cur), wc * 64 + j * 16, ks, lane);
+      load_frags4<AK, false>(ldsA(cur), wr * 64, ks, lane, af);
+      load_frags4<BKM, false>(ldsB(cur), wc * 64, ks, lane, bfr);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -596,16 +638,13 @@ __device__ __forceinline__ const bf16_t* glds_src32(const bf16_t* base, long ld,
   }
 }
 
-// fragment (16 rows from r0, all 32 k of the stage)
+// k-major fragment (16 rows from r0, all 32 k of a BK = 32 stage)
 template <bool KMAJOR>
 __device__ __forceinline__ bf16x8 load_frag32(const char* lds, int r0, int lane) {
-  if (KMAJOR) {
-    const int row = r0 + (lane & 15);
-    const int c = lane >> 4;
-    return *reinterpret_cast<const bf16x8*>(lds + row * 64 + ((c ^ ksw32(row)) << 4));
-  } else {
-    return load_frag16<false>(lds, r0, 0, lane);
-  }
+  static_assert(KMAJOR, "mn-major fragments go through load_frags4 (tr_read_pair)");
+  const int row = r0 + (lane & 15);
+  const int c = lane >> 4;
+  return *reinterpret_cast<const bf16x8*>(lds + row * 64 + ((c ^ ksw32(row)) << 4));
 }
 
 // 16-byte output store with a cache policy: 0 plain, 1 non-temporal (nt), 2 write-through (sc1).
@@ -663,26 +702,46 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
     constexpr int CPL = sizeof(OutT) == 2 ? 8 : 4;          // columns per lane (16 B of output)
     constexpr int LPR = 64 / CPL;                           // lanes per row
     constexpr int RPI = 64 / LPR;                           // rows per iteration
+    constexpr int NIT = 16 * NI / RPI;
     const int lr = lane / LPR, lc = (lane % LPR) * CPL;
+    const long n = nbase + lc;
+    if (fast) {
+      // The loads of a row group (residual rows, saved pre-activations) are issued one group AHEAD of the
+      // stores: the compiler cannot move a load above a store that might alias it, and a load placed after a
+      // store waits (vmcnt is in-order and counts stores) for that store's whole round trip to HBM.
+      float4 bv[CPL / 4];
 #pragma unroll
-    for (int it = 0; it < 16 * NI / RPI; ++it) {
-      const int row = it * RPI + lr;
-      const long m = mbase + Q * 16 + row, n = nbase + lc;
-      if (m >= p.M) continue;
-      float a[CPL];
-#pragma unroll
-      for (int c4 = 0; c4 < CPL / 4; ++c4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * WEPI_LD + lc + 4 * c4);
-        a[4 * c4] = t[0]; a[4 * c4 + 1] = t[1]; a[4 * c4 + 2] = t[2]; a[4 * c4 + 3] = t[3];
-      }
-      if (fast) {
+      for (int c4 = 0; c4 < CPL / 4; ++c4)
+        bv[c4] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      f32x4 res[2][CPL / 4];                                // ping-pong: the loads of row group it + 1 are issued
+      typedef typename std::conditional<sizeof(InT) == 4, f32x4, bf16x4>::type aux4_t;
+      aux4_t aux[2][CPL / 4];                               // before the stores of row group it
+      auto preload = [&](int it) {
+        long m = mbase + Q * 16 + it * RPI + lr;
+        m = m < p.M ? m : p.M - 1;                          // rows past M: load a valid row, never store
 #pragma unroll
         for (int c4 = 0; c4 < CPL / 4; ++c4) {
-          float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + n + 4 * c4);
-          a[4 * c4] = fmaf(a[4 * c4], alpha, b.x); a[4 * c4 + 1] = fmaf(a[4 * c4 + 1], alpha, b.y);
-          a[4 * c4 + 2] = fmaf(a[4 * c4 + 2], alpha, b.z); a[4 * c4 + 3] = fmaf(a[4 * c4 + 3], alpha, b.w);
+          if constexpr (sizeof(OutT) == 4) {               // (bf16 outputs with a residual are rare: loaded in place below)
+            if (p.residual) res[it & 1][c4] = *reinterpret_cast<const f32x4*>(p.residual + m * p.ld_res + n + 4 * c4);
+          }
+          if (p.act == FAVIT_ACT_DGELU)
+            aux[it & 1][c4] = *reinterpret_cast<const aux4_t*>(reinterpret_cast<const InT*>(p.aux_in) + m * p.ld_aux_in + n + 4 * c4);
         }
+      };
+      preload(0);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (it + 1 < NIT) preload(it + 1);
+        const int row = it * RPI + lr;
+        const long m = mbase + Q * 16 + row;
+        float a[CPL];
+#pragma unroll
+        for (int c4 = 0; c4 < CPL / 4; ++c4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * WEPI_LD + lc + 4 * c4);
+          a[4 * c4] = fmaf(t[0], alpha, bv[c4].x); a[4 * c4 + 1] = fmaf(t[1], alpha, bv[c4].y);
+          a[4 * c4 + 2] = fmaf(t[2], alpha, bv[c4].z); a[4 * c4 + 3] = fmaf(t[3], alpha, bv[c4].w);
+        }
+        if (m >= p.M) continue;
         auto store_vec = [&](OutT* dst) {
           uint4 raw;
           if constexpr (sizeof(OutT) == 4) {
@@ -695,28 +754,15 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
           }
           store16_policy(dst, raw, p.store_policy);
         };
-        if (p.aux_out && p.dbg != 4) store_vec(reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n);
-        if (p.act == FAVIT_ACT_GELU && p.dbg != 5) {
+        if (p.aux_out) store_vec(reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n);
+        if (p.act == FAVIT_ACT_GELU) {
 #pragma unroll
           for (int c = 0; c < CPL; ++c) a[c] = epi_gelu<InT>(a[c]);
         } else if (p.act == FAVIT_ACT_DGELU) {
-          const InT* ai = reinterpret_cast<const InT*>(p.aux_in) + m * p.ld_aux_in + n;
-          float x[CPL];
-          if constexpr (sizeof(InT) == 4) {
 #pragma unroll
-            for (int c4 = 0; c4 < CPL / 4; ++c4) {
-              const f32x4 t = *reinterpret_cast<const f32x4*>(ai + 4 * c4);
-              x[4 * c4] = t[0]; x[4 * c4 + 1] = t[1]; x[4 * c4 + 2] = t[2]; x[4 * c4 + 3] = t[3];
-            }
-          } else {
+          for (int c4 = 0; c4 < CPL / 4; ++c4)
 #pragma unroll
-            for (int c4 = 0; c4 < CPL / 4; ++c4) {
-              const bf16x4 t = *reinterpret_cast<const bf16x4*>(ai + 4 * c4);
-              x[4 * c4] = (float)t[0]; x[4 * c4 + 1] = (float)t[1]; x[4 * c4 + 2] = (float)t[2]; x[4 * c4 + 3] = (float)t[3];
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) a[c] *= epi_dgelu<InT>(x[c]);
+            for (int c = 0; c < 4; ++c) a[4 * c4 + c] *= epi_dgelu<InT>((float)aux[it & 1][c4][c]);
         }
         if (p.drop_thresh) {
 #pragma unroll
@@ -726,16 +772,24 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
         if (p.residual) {
 #pragma unroll
           for (int c4 = 0; c4 < CPL / 4; ++c4) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(p.residual + m * p.ld_res + n + 4 * c4);
+            f32x4 r;
+            if constexpr (sizeof(OutT) == 4) r = res[it & 1][c4];
+            else r = *reinterpret_cast<const f32x4*>(p.residual + m * p.ld_res + n + 4 * c4);
             a[4 * c4] += r[0]; a[4 * c4 + 1] += r[1]; a[4 * c4 + 2] += r[2]; a[4 * c4 + 3] += r[3];
           }
         }
         store_vec(C + m * p.ldc + n);
-      } else {
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + lr;
+        const long m = mbase + Q * 16 + row;
+        if (m >= p.M) continue;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
           if (n + c >= p.N) continue;
-          float v = a[c] * alpha;
+          float v = wl[row * WEPI_LD + lc + c] * alpha;
           if (p.bias) v += p.bias[n + c];
           if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n + c] = from_f32<OutT>(v);
           if (p.act == FAVIT_ACT_GELU) v = epi_gelu<InT>(v);
@@ -870,10 +924,14 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
     const int ra = AK ? wr * 64 : (wr & 1) * 64;
     const char* lb = st + P4_A_BYTES;
     bf16x8 af[4], bfr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = load_frag32<AK>(la, ra + i * 16, lane);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bfr[j] = load_frag32<BKM>(lb, wc * 64 + j * 16, lane);
+    // k-major operand first: its compiler-tracked ds_read_b128 are in flight while the transposed reads issue
+    if constexpr (AK || !BKM) {
+      load_frags4<AK, true>(la, ra, 0, lane, af);
+      load_frags4<BKM, true>(lb, wc * 64, 0, lane, bfr);
+    } else {
+      load_frags4<BKM, true>(lb, wc * 64, 0, lane, bfr);
+      load_frags4<AK, true>(la, ra, 0, lane, af);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1102,8 +1160,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_s64_kernel(KParams p) {
       bf16x8 af[2], bfr[4];
 #pragma unroll
       for (int i = 0; i < 2; ++i) af[i] = load_frag16<true>(la, wr * 32 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = load_frag16<BKM>(lb, wc * 64 + j * 16, ks, lane);
+      load_frags4<BKM, false>(lb, wc * 64, ks, lane, bfr);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
