@@ -192,6 +192,14 @@ __device__ __forceinline__ void tr_fence(u32x2_t (&l)[4], u32x2_t (&h)[4]) {
                : "memory");
 }
 
+__device__ __forceinline__ void tr_fence2(u32x2_t (&l)[4], u32x2_t (&h)[4], u32x2_t (&l2)[4], u32x2_t (&h2)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]), "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]),
+                 "+v"(l2[0]), "+v"(l2[1]), "+v"(l2[2]), "+v"(l2[3]), "+v"(h2[0]), "+v"(h2[1]), "+v"(h2[2]), "+v"(h2[3])
+               :
+               : "memory");
+}
+
 __device__ __forceinline__ bf16x8 tr_pack(const u32x2_t& lo, const u32x2_t& hi) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
   const u32x4_t r = {lo.x, lo.y, hi.x, hi.y};
@@ -925,8 +933,17 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
     const char* lb = st + P4_A_BYTES;
     bf16x8 af[4], bfr[4];
     // k-major operand first: its compiler-tracked ds_read_b128 are in flight while the transposed reads issue
-    if constexpr (AK || !BKM) {
-      load_frags4<AK, true>(la, ra, 0, lane, af);
+    if constexpr (!AK && !BKM) {               // weight gradients: all 16 transposed reads in flight, one wait
+      u32x2_t al[4], ah[4], bl[4], bh[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tr_read_pair(la, ra + i * 16, 0, lane, al[i], ah[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tr_read_pair(lb, wc * 64 + j * 16, 0, lane, bl[j], bh[j]);
+      tr_fence2(al, ah, bl, bh);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { af[i] = tr_pack(al[i], ah[i]); bfr[i] = tr_pack(bl[i], bh[i]); }
+    } else if constexpr (AK) {
+      load_frags4<true, true>(la, ra, 0, lane, af);
       load_frags4<BKM, true>(lb, wc * 64, 0, lane, bfr);
     } else {
       load_frags4<BKM, true>(lb, wc * 64, 0, lane, bfr);
