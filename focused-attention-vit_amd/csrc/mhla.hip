@@ -223,6 +223,7 @@ struct AttnArgs {
   const uint8_t* mask;
   int B, L, H, hd, W;
   int rb;              // backward: key rows per workgroup (attn_entry sizes it to the LDS regions)
+  int qcap;            // backward: rows of the Q / dO images and of the dS / P tables (>= rb + 3h + 1)
   int dbg;             // experiments only (FAVIT_MHLA_DBG)
   float inv_sqrt_hd;   // unused (true division is applied), kept for clarity
   uint32_t thresh;
@@ -351,9 +352,9 @@ __global__ __launch_bounds__(256) void mhla_bwd_kernel(AttnArgs a) {
   char* ldsK = smem;
   char* ldsV = ldsK + imK.n_rows * rs;
   char* ldsQ = ldsV + imK.n_rows * rs;
-  char* ldsG = ldsQ + 64 * rs;                               // dO rows
-  float* tds = reinterpret_cast<float*>(ldsG + 64 * rs);     // [64][WMAX] dS / sqrt(hd)
-  float* tp = tds + 64 * WMAX;                               // [64][WMAX] P after dropout
+  char* ldsG = ldsQ + a.qcap * rs;                           // dO rows
+  float* tds = reinterpret_cast<float*>(ldsG + a.qcap * rs); // [qcap][WMAX] dS / sqrt(hd)
+  float* tp = tds + a.qcap * WMAX;                           // [qcap][WMAX] P after dropout
 
   {
     constexpr int CPR = HD * (int)sizeof(T) / 16;
@@ -1106,7 +1107,7 @@ int launch_attn(bool bwd, const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, a);
   } else {
     const int krows = (a.rb + 4 * h) + 2 * (2 * h + 1);
-    const size_t lds = (size_t)2 * krows * rs + (size_t)2 * 64 * rs + (size_t)2 * 64 * WMAX * 4;
+    const size_t lds = (size_t)2 * krows * rs + (size_t)2 * a.qcap * rs + (size_t)2 * a.qcap * WMAX * 4;
     if (lds > 160 * 1024) return FAVIT_ERR_UNSUPPORTED;
     auto k = mhla_bwd_kernel<T, DPL, WMAX>;
     if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1144,10 +1145,17 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
     int rb_max = 64 - 3 * h - 1;
     if (80 - 8 * h - 2 < rb_max) rb_max = 80 - 8 * h - 2;
     if (rb_max < 1) return FAVIT_ERR_UNSUPPORTED;
-    const int nblk = (L + rb_max - 1) / rb_max;
+    // One block if the sequence fits.  Otherwise blocks whose band rows (rb + 2h) fill exactly one 32-row
+    // pass of phase 1, balanced over L: less LDS per workgroup (6 resident instead of 4 at hd = 64, W = 7)
+    // outweighs the extra halo staging (measured at L = 197: rb 25 -> 127 us, rb 50 -> 133 us, rb 33 -> 158 us).
+    int target = rb_max;
+    if (L > rb_max && 32 - 2 * h >= 8 && 32 - 2 * h < rb_max) target = 32 - 2 * h;
+    const int nblk = (L + target - 1) / target;
     a.rb = (L + nblk - 1) / nblk;
     const char* e = getenv("FAVIT_MHLA_RB");
     if (e && atoi(e) > 0 && atoi(e) <= rb_max) a.rb = atoi(e);
+    a.qcap = a.rb + 3 * h + 1;                 // band rows + the wrap rows a first / last block adds
+    if (a.qcap > 64) a.qcap = 64;
   }
   { const char* e = getenv("FAVIT_MHLA_DBG"); a.dbg = e ? atoi(e) : 0; }
   a.inv_sqrt_hd = 0.f;
