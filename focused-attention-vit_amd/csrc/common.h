@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "favit.h"
 
 typedef __bf16 bf16_t;
@@ -21,6 +24,20 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
   } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a (kernel, device) pair: it is set once per
+// pair (any number of devices per process, any number of host threads), not once per process.
+static inline void favit_ensure_dyn_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& e : done)
+    if (e.first == kernel && e.second == dev) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.emplace_back(kernel, dev);
+}
 
 template <typename T> struct dtype_of;
 template <> struct dtype_of<float> { static constexpr int value = FAVIT_F32; };

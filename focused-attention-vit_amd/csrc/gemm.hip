@@ -64,7 +64,9 @@ struct KParams {
   int ntiles;          // output tiles per (split, batch)
   int xcd_split;       // 1: 1-D grid of ntiles*nsplit blocks, all tiles of a split on one XCD
   int store_policy;    // cache policy of the epilogue's output stores (store16_policy)
-  int dbg;     // experiments only (FAVIT_GEMM_DBG): 1 = skip epilogue, 2 = skip main loop
+#ifdef FAVIT_PROBE
+  int dbg;     // probe build only (make probe; tools/): 1 = skip epilogue, 2 = skip main loop
+#endif
   const float* scale_a;   // fp8 operands: device dequantisation factors (or null)
   const float* scale_b;
 };
@@ -860,7 +862,11 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
   OutT* C = reinterpret_cast<OutT*>(p.C) + zo * p.sCo + zi * p.sCi;
   const long kbeg = (long)split * p.k_per_split;
   const long kend = min(p.K, kbeg + p.k_per_split);
+#ifdef FAVIT_PROBE
   const int nk = p.dbg == 2 ? 0 : (int)((kend - kbeg) / SBK);
+#else
+  const int nk = (int)((kend - kbeg) / SBK);
+#endif
   const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0) && (wc == 0);
   f32x4 racc[4];
 #pragma unroll
@@ -966,6 +972,7 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
       if (m < p.M) atomicAdd(p.a_rowsum + m, racc[i][0]);
     }
   }
+#ifdef FAVIT_PROBE
   if (p.dbg == 1) {
     float s = 0.f;
 #pragma unroll
@@ -975,6 +982,7 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
     if (s == 12345.678f) C[0] = from_f32<OutT>(s);
     return;
   }
+#endif
   float alpha = p.alpha;
   if (F8) {
     if (p.scale_a) alpha *= p.scale_a[0];
@@ -1029,7 +1037,11 @@ __global__ __launch_bounds__(P7_THREADS) void gemm_bf16_p7_kernel(KParams p) {
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
   const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B);
   OutT* C = reinterpret_cast<OutT*>(p.C);
+#ifdef FAVIT_PROBE
   const int nk = p.dbg == 2 ? 0 : (int)(p.K / P4_BK);
+#else
+  const int nk = (int)(p.K / P4_BK);
+#endif
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -1073,6 +1085,7 @@ __global__ __launch_bounds__(P7_THREADS) void gemm_bf16_p7_kernel(KParams p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     cur = cur == 2 ? 0 : cur + 1;
   }
+#ifdef FAVIT_PROBE
   if (p.dbg == 1) {
     float s = 0.f;
 #pragma unroll
@@ -1082,6 +1095,7 @@ __global__ __launch_bounds__(P7_THREADS) void gemm_bf16_p7_kernel(KParams p) {
     if (s == 12345.678f) C[0] = from_f32<OutT>(s);
     return;
   }
+#endif
   __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
   float* wl = reinterpret_cast<float*>(smem + wave * WEPI_Q_BYTES);
   const long mb = m0 + wr * 64, nb = n0 + wc * 64;
@@ -1093,15 +1107,7 @@ __global__ __launch_bounds__(P7_THREADS) void gemm_bf16_p7_kernel(KParams p) {
 
 template <typename Kn>
 int launch_p7(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
-  static const void* seen[8];
-  static int nseen = 0;
-  const void* kptr = reinterpret_cast<const void*>(kernel);
-  bool known = false;
-  for (int i = 0; i < nseen; ++i) known = known || seen[i] == kptr;
-  if (!known) {
-    (void)hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, P7_LDS);
-    if (nseen < 8) seen[nseen++] = kptr;
-  }
+  favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), P7_LDS);
   hipLaunchKernelGGL(kernel, grid, dim3(P7_THREADS), P7_LDS, st, kp);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
@@ -1193,15 +1199,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_s64_kernel(KParams p) {
 
 template <typename Kn>
 int launch_s64(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
-  static const void* seen[8];
-  static int nseen = 0;
-  const void* kptr = reinterpret_cast<const void*>(kernel);
-  bool known = false;
-  for (int i = 0; i < nseen; ++i) known = known || seen[i] == kptr;
-  if (!known) {
-    (void)hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, S64_LDS);
-    if (nseen < 8) seen[nseen++] = kptr;
-  }
+  favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), S64_LDS);
   hipLaunchKernelGGL(kernel, grid, dim3(NTHREADS), S64_LDS, st, kp);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
@@ -1230,16 +1228,7 @@ __global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_grouped_tn_kernel(
 
 template <typename Kn>
 int launch_p4(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
-  // one attribute call per distinct kernel (all instantiations share this function's type)
-  static const void* seen[32];
-  static int nseen = 0;
-  const void* kptr = reinterpret_cast<const void*>(kernel);
-  bool known = false;
-  for (int i = 0; i < nseen; ++i) known = known || seen[i] == kptr;
-  if (!known) {
-    (void)hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS);
-    if (nseen < 32) seen[nseen++] = kptr;
-  }
+  favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), P4_LDS);
   hipLaunchKernelGGL(kernel, grid, dim3(P4_THREADS), P4_LDS, st, kp);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
@@ -1422,11 +1411,7 @@ __global__ void zero_c_kernel(float* C, long M, long N, long ldc, long sCo, long
 
 template <typename K>
 int launch(K kernel, const KParams& kp, dim3 grid, hipStream_t st) {
-  static bool attr_set = false;   // one flag per kernel instantiation
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
+  favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), LDS_BYTES);
   hipLaunchKernelGGL(kernel, grid, dim3(NTHREADS), LDS_BYTES, st, kp);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
@@ -1434,13 +1419,18 @@ int launch(K kernel, const KParams& kp, dim3 grid, hipStream_t st) {
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-// Experiment switches (tools/README.md), read once per process.
+// Kernel-selection switches (tools/README.md), read once per process.  Every selectable kernel computes the
+// same result; the work-skipping probe switch (FAVIT_GEMM_DBG) exists only in the `make probe` build.
 struct GemmKnobs {
   int dbg, store_policy;
   bool force128, no_p4, no_p7, no_s64;
   GemmKnobs() {
     const char* e;
+#ifdef FAVIT_PROBE
     dbg = (e = getenv("FAVIT_GEMM_DBG")) ? atoi(e) : 0;
+#else
+    dbg = 0;
+#endif
     store_policy = (e = getenv("FAVIT_GEMM_STORE")) ? atoi(e) : 1;
     force128 = getenv("FAVIT_GEMM_TILE128") != nullptr;
     no_p4 = getenv("FAVIT_GEMM_NO_P4") != nullptr;
@@ -1538,7 +1528,9 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.alpha = g->alpha;
   kp.scale_a = fp8 ? g->scale_a : nullptr;
   kp.scale_b = fp8 ? g->scale_b : nullptr;
+#ifdef FAVIT_PROBE
   kp.dbg = knobs().dbg;
+#endif
   // epilogue outputs / residual / aux reads are touched once: non-temporal keeps them from evicting
   // the operand panels the co-resident workgroups share in L2 (fc2: 140 -> 114 us)
   kp.store_policy = knobs().store_policy;
@@ -1728,7 +1720,10 @@ extern "C" int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void
     kp.xcd_split = 1;
     kp.alpha = 1.0f;
     kp.drop_thresh = 0; kp.drop_scale = 1.0f; kp.drop_seed = 0;
-    kp.store_policy = 0; kp.dbg = 0;
+    kp.store_policy = 0;
+#ifdef FAVIT_PROBE
+    kp.dbg = 0;
+#endif
     gp.tile_off[i] = off;
     off += kp.ntiles;
   }
@@ -1757,12 +1752,7 @@ extern "C" int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void
       FAVIT_CHECK_LAUNCH();
     }
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_p4_grouped_tn_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, P4_LDS);
-    attr_set = true;
-  }
+  favit_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_p4_grouped_tn_kernel), P4_LDS);
   hipLaunchKernelGGL(gemm_bf16_p4_grouped_tn_kernel, dim3((unsigned)(off * nsplit)), dim3(P4_THREADS), P4_LDS, st, gp);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;

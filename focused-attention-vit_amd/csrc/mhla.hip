@@ -224,7 +224,9 @@ struct AttnArgs {
   int B, L, H, hd, W;
   int rb;              // backward: key rows per workgroup (attn_entry sizes it to the LDS regions)
   int qcap;            // backward: rows of the Q / dO images and of the dS / P tables (>= rb + 3h + 1)
-  int dbg;             // experiments only (FAVIT_MHLA_DBG)
+#ifdef FAVIT_PROBE
+  int dbg;             // probe build only (make probe; tools/): skips work, never in libfavit.so
+#endif
   float inv_sqrt_hd;   // unused (true division is applied), kept for clarity
   uint32_t thresh;
   float keep_scale;
@@ -536,7 +538,9 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
   }
   __syncthreads();
 
+#ifdef FAVIT_PROBE
   if (a.dbg == 1) return;
+#endif
   const int t0 = r0 + 16 * wave;
   if (t0 >= r1) return;                                // whole wave idle (no barrier after this point)
   const int i = t0 + qi;
@@ -620,7 +624,11 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
     vv[4] = hi4[0]; vv[5] = hi4[1]; vv[6] = hi4[2]; vv[7] = hi4[3];
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o, 0, 0, 0);
+#ifdef FAVIT_PROBE
     if (qvalid && (a.dbg != 2 || o[0] == 12345.f)) {
+#else
+    if (qvalid) {
+#endif
       bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
       *reinterpret_cast<bf16x4*>(orow + 16 * dt + 4 * g) = ob;
     }
@@ -1157,7 +1165,9 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
     a.qcap = a.rb + 3 * h + 1;                 // band rows + the wrap rows a first / last block adds
     if (a.qcap > 64) a.qcap = 64;
   }
+#ifdef FAVIT_PROBE
   { const char* e = getenv("FAVIT_MHLA_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
   a.inv_sqrt_hd = 0.f;
   a.thresh = dropout_threshold(p);
   a.keep_scale = 1.0f / (1.0f - p);

@@ -357,8 +357,10 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
   for (int c = lane; c < C; c += 64) s += __expf(lr[c] - m);
   s = wave_sum(s);
   const float lse = m + __logf(s);
-  const int lab = (int)labels[row];
-  if (lane == 0) loss_rows[row] = lse - lr[lab];
+  const int64_t lab64 = labels[row];
+  const bool lab_ok = lab64 >= 0 && lab64 < C;       // out of range (e.g. ignore_index): NaN row, never an OOB read
+  const int lab = lab_ok ? (int)lab64 : -1;
+  if (lane == 0) loss_rows[row] = lab_ok ? lse - lr[lab] : __builtin_nanf("");
   if (dlogits) {
     const float inv = 1.0f / s;
     for (int c = lane; c < C; c += 64)

@@ -8,8 +8,11 @@ no cross-sample op).  Design for xGMI (7 point-to-point links per GPU, no switch
     so a bucket is a slice -- no gather/scatter copies around the collective;
   * few, large buckets (default 32 MiB): on a fully connected 8-GPU node RCCL's all-reduce is
     per-link bound, so large messages amortise the per-collective launch + latency;
-  * a bucket's all-reduce is issued (async, on RCCL's own stream) as soon as the last gradient
-    in it has been accumulated, which overlaps it with the rest of backward.
+  * a bucket's all-reduce is issued (async, on RCCL's own stream) as soon as every parameter in it
+    has reported a gradient (a set of parameters, not a count of events: a parameter used twice in
+    one forward reports twice), which overlaps it with the rest of backward.  Gradient accumulation
+    over several backward passes must wrap all but the last in ``no_sync()``; a gradient that arrives
+    after its bucket was launched raises instead of producing rank-divergent sums.
 """
 from __future__ import annotations
 
@@ -96,20 +99,43 @@ class GradSync:
         if i is not None and self.world > 1:
             self._make_hook(i)(p)
 
+    def no_sync(self):
+        """Context manager for gradient accumulation: backward passes inside it only accumulate into the
+        flat buffer; no bucket is launched.  The LAST micro-batch's backward runs outside it (its
+        ready events launch the buckets, overlapped with that backward), or call finish() directly."""
+        sync = self
+
+        class _NoSync:
+            def __enter__(self):
+                self.prev, sync.defer = sync.defer, True
+
+            def __exit__(self, *exc):
+                sync.defer = self.prev
+                return False
+        return _NoSync()
+
     def _make_hook(self, i):
         def hook(_p):
-            if self.defer:             # graph capture / replay: finish() launches every bucket afterwards
+            if self.defer:             # graph capture / replay / no_sync(): finish() launches every bucket afterwards
                 return
             b = self._bucket_of[i]
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
+            if self._launched[b]:
+                # A gradient arrived for a bucket whose all-reduce is already in flight: a second backward
+                # before step() (gradient accumulation without no_sync()) or a parameter used twice in one
+                # forward.  The reduced values would miss this contribution and differ across ranks.
+                raise RuntimeError(
+                    "GradSync: gradient of a parameter accumulated after its bucket's all-reduce was launched; "
+                    "wrap all but the last backward of a step in GradSync.no_sync() (FusedAdamW.no_sync())")
+            self._seen[b].add(i)
+            if len(self._seen[b]) == self._pending[b]:
                 self._launch(b)
         return hook
 
     def reset(self):
         for b, (_, _, idxs) in enumerate(self.buckets):
-            self._pending[b] = len(idxs)
+            self._pending[b] = len(idxs)          # distinct parameters whose gradient must have arrived
             self._launched[b] = False
+        self._seen = [set() for _ in self.buckets]
         self._handles = []
 
     def _launch(self, b):

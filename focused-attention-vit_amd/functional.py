@@ -144,21 +144,64 @@ def get_compute_dtype() -> torch.dtype:
     return _STATE["cdt"]
 
 
-def bump_weight_epoch() -> None:
-    """Called by optimizers that update parameters through raw pointers."""
+def bump_weight_epoch(synced_mirrors=()) -> None:
+    """Called by optimizers that update parameters through raw pointers.  synced_mirrors: the bf16
+    mirrors the caller has just rewritten itself (they stay valid across the bump)."""
     _STATE["epoch"] += 1
+    for m in synced_mirrors:
+        m.epoch = _STATE["epoch"]
 
 
 # parameter storage -> (fp32 flat buffer, bf16 mirror) kept fresh by the fused optimizer (train.FusedAdamW)
-_LP_MIRRORS = []
+class _LPMirror:
+    """bf16 mirror ``lp`` of the flat fp32 parameter buffer ``flat_p`` of one optimizer group.
+
+    The owner (train.FusedAdamW) rewrites it inside the AdamW kernel and tells the mirror so
+    (``mark_synced``).  Every other way of editing a parameter is detected when the parameter is next
+    used: ``load_state_dict`` / ``nn.init.*`` / ``p.copy_`` bump the tensor's version counter (compared
+    per parameter), ``invalidate_weight_cache()`` bumps the weight epoch (compared per mirror; needed
+    for ``p.data.copy_``, which no counter sees).  A stale slice / mirror is re-cast before it is returned."""
+    __slots__ = ("flat_ref", "lp", "epoch", "versions", "params")
+
+    def __init__(self, flat_p, lp, params=()):
+        self.flat_ref, self.lp, self.params = weakref.ref(flat_p), lp, [weakref.ref(p) for p in params]
+        self.mark_synced()
+
+    def mark_synced(self):
+        """The owner has just rewritten the whole mirror from flat_p (AdamW kernel or a cast): every
+        parameter's current version counter is the one the mirror reflects."""
+        self.epoch = _STATE["epoch"]
+        self.versions = {id(p): p._version for p in (r() for r in self.params) if p is not None}
+
+    def lookup(self, src, w):
+        fp = self.flat_ref()
+        if fp is None:
+            return None
+        base, ptr = fp.data_ptr(), w.data_ptr()
+        if not (base <= ptr < base + 4 * fp.numel()):
+            return False
+        if self.epoch != _STATE["epoch"]:                 # explicit invalidation: refresh the whole mirror once
+            K.cast(fp, torch.bfloat16, out=self.lp)
+            self.epoch = _STATE["epoch"]
+        off = (ptr - base) // 4
+        view = self.lp[off:off + w.numel()].view(w.shape)
+        key = id(src)
+        ver = src._version
+        if self.versions.get(key, ver) != ver:            # edited in place since the last use: re-cast this slice
+            K.cast(w, torch.bfloat16, out=view)
+        self.versions[key] = ver
+        return view
 
 
-def register_lp_mirror(flat_p: torch.Tensor, flat_lp: torch.Tensor) -> None:
-    """flat_lp is a bf16 mirror of the fp32 parameter buffer flat_p.  The owner (train.FusedAdamW)
-    keeps it fresh: the AdamW kernel rewrites it with every update and zero_grad() re-casts it, so
-    parameters edited in place between steps (``.data.copy_``, ``nn.init.*``) are picked up at the
-    next zero_grad()."""
-    _LP_MIRRORS.append((weakref.ref(flat_p), flat_lp))
+_LP_MIRRORS: List[_LPMirror] = []
+
+
+def register_lp_mirror(flat_p: torch.Tensor, flat_lp: torch.Tensor, params=()) -> _LPMirror:
+    """flat_lp is a bf16 mirror of the fp32 parameter buffer flat_p, just cast from it; params are the
+    nn.Parameters living in flat_p (see _LPMirror)."""
+    m = _LPMirror(flat_p, flat_lp, params)
+    _LP_MIRRORS.append(m)
+    return m
 
 
 def clear_lp_mirrors() -> None:
@@ -166,10 +209,10 @@ def clear_lp_mirrors() -> None:
 
 
 def invalidate_weight_cache() -> None:
-    """Drop every cached compute-dtype copy of a parameter.  Needed only after editing parameters
-    through ``.data`` (``p.data.copy_(...)``), which autograd's version counter cannot see, once a
-    bf16-mode forward has already run; ``load_state_dict``, ``nn.init.*`` and optimizer steps are
-    detected automatically."""
+    """Drop every cached compute-dtype copy of a parameter (per-tensor caches and the fused optimizer's
+    bf16 mirrors alike).  Needed only after editing parameters through ``.data`` (``p.data.copy_(...)``),
+    which autograd's version counter cannot see; ``load_state_dict``, ``nn.init.*``, ``p.copy_`` and
+    optimizer steps are detected automatically."""
     _STATE["epoch"] += 1
 
 
@@ -183,16 +226,12 @@ def wcast(w: torch.Tensor) -> torch.Tensor:
     if w.dtype == cdt and w.is_contiguous():
         return w
     if cdt == torch.bfloat16 and w.dtype == torch.float32 and w.is_contiguous():
-        ptr = w.data_ptr()
-        for ref, lp in list(_LP_MIRRORS):
-            fp = ref()
-            if fp is None:                    # the optimizer that owned this mirror is gone
-                _LP_MIRRORS.remove((ref, lp))
-                continue
-            base = fp.data_ptr()
-            if base <= ptr < base + 4 * fp.numel():
-                off = (ptr - base) // 4
-                return lp[off:off + w.numel()].view(w.shape)
+        for m in list(_LP_MIRRORS):
+            hit = m.lookup(src, w)
+            if hit is None:                   # the optimizer that owned this mirror is gone
+                _LP_MIRRORS.remove(m)
+            elif hit is not False:
+                return hit
     tag = (w.data_ptr(), tuple(w.shape), w._version, _STATE["epoch"], cdt)
     hit = getattr(src, "_favit_cast", None)
     if hit is not None and hit[0] == tag:
@@ -754,21 +793,26 @@ class EncoderOp:
         g_lp = _as_cdt(g)
         grads = []
         begin_wgrads()
-        for bs, tp in zip(reversed(self.blocks), reversed(tapes)):
-            x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm = tp
-            dxn2, gm = bs.mlp.bwd(sm, g_lp)
-            g, g_lp, dg2, db2 = K.layernorm_bwd(dxn2, x1, D, g2, mu2, rs2, M, D, dres=g, want_lp=True,
-                                                dg_out=_gt(g2), db_out=_gt(b2))
-            if dg2 is None:
-                _ready(g2, b2)
-            dxn1, ga = bs.attn.bwd(sa, g_lp)
-            g, g_lp, dg1, db1 = K.layernorm_bwd(dxn1, x, D, g1, mu1, rs1, M, D, dres=g, want_lp=True,
-                                                dg_out=_gt(g1), db_out=_gt(b1))
-            if dg1 is None:
-                _ready(g1, b1)
-            flush_wgrads()
-            join_side_stream()
-            grads = [dg1, db1] + ga + [dg2, db2] + gm + grads
+        try:
+            for bs, tp in zip(reversed(self.blocks), reversed(tapes)):
+                x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm = tp
+                dxn2, gm = bs.mlp.bwd(sm, g_lp)
+                g, g_lp, dg2, db2 = K.layernorm_bwd(dxn2, x1, D, g2, mu2, rs2, M, D, dres=g, want_lp=True,
+                                                    dg_out=_gt(g2), db_out=_gt(b2))
+                if dg2 is None:
+                    _ready(g2, b2)
+                dxn1, ga = bs.attn.bwd(sa, g_lp)
+                g, g_lp, dg1, db1 = K.layernorm_bwd(dxn1, x, D, g1, mu1, rs1, M, D, dres=g, want_lp=True,
+                                                    dg_out=_gt(g1), db_out=_gt(b1))
+                if dg1 is None:
+                    _ready(g1, b1)
+                flush_wgrads()
+                join_side_stream()
+                grads = [dg1, db1] + ga + [dg2, db2] + gm + grads
+        except BaseException:
+            _WG["list"] = None                # drop the half-collected weight gradients of the failed backward
+            _SIDE["pending"].clear()
+            raise
         end_wgrads()
         return [g.reshape(B, L, D)], grads
 

@@ -32,11 +32,23 @@ def dt(t_or_dtype) -> int:
 
 
 def require_gpu(*ts):
+    """Every tensor must live on the CURRENT ROCm device: kernels are launched on the current device's
+    current stream (_st), so a tensor of another device would be dereferenced on the wrong GPU."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError(
                 "focused-attention-vit_amd runs its hot path in HIP kernels on an MI355X; got a CPU tensor. "
                 "There is no CPU fallback (move the module and its inputs to the GPU).")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(
+                f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: one process drives one GPU "
+                "(torch.cuda.set_device(local_rank) before building the model), or wrap the call in "
+                "`with torch.cuda.device(t.device):`")
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -397,7 +409,12 @@ def sppp_posenc_fwd(x, cent):
 def cross_entropy(logits, labels, grad_scale=None):
     """Returns (loss_rows[B], dlogits or None)."""
     require_gpu(logits, labels)
+    if logits.dim() != 2 or logits.dtype != torch.float32 or not logits.is_contiguous():
+        raise TypeError("cross_entropy: logits must be a contiguous fp32 [B, C] tensor")
     B, Cn = logits.shape
+    if labels.dtype != torch.int64 or tuple(labels.shape) != (B,) or not labels.is_contiguous():
+        raise TypeError("cross_entropy: labels must be a contiguous int64 [B] tensor of class indices "
+                        "(out-of-range labels, e.g. ignore_index = -100, give a NaN loss row)")
     loss_rows = torch.empty(B, dtype=torch.float32, device=logits.device)
     dlog = torch.empty_like(logits) if grad_scale is not None else None
     _abi.check(_abi.lib().favit_cross_entropy(_p(logits), _p(labels), _p(loss_rows), _p(dlog), B, Cn,

@@ -79,20 +79,32 @@ class FusedAdamW:
                 "lp": torch.empty(flat.numel, dtype=torch.bfloat16, device=flat.flat_p.device) if flat.flat_p.is_cuda else None,
                 "sync": GradSync(flat, bucket_mb) if dist_on else None,
             })
+            self.groups[-1]["mirror"] = None
             if self.groups[-1]["lp"] is not None:
                 K.cast(flat.flat_p, torch.bfloat16, out=self.groups[-1]["lp"])
-                F.register_lp_mirror(flat.flat_p, self.groups[-1]["lp"])
+                self.groups[-1]["mirror"] = F.register_lp_mirror(flat.flat_p, self.groups[-1]["lp"], flat.params)
         self.steps = 0
         self.world = torch.distributed.get_world_size() if dist_on else 1
         syncs = [g["sync"] for g in self.groups if g["sync"] is not None]
         if syncs:
             F.set_grad_ready_hook(lambda p: [s.grad_ready(p) for s in syncs])
 
+    def no_sync(self):
+        """Gradient accumulation under data parallelism: ``with opt.no_sync(): loss.backward()`` for every
+        micro-batch but the last (dp.GradSync.no_sync)."""
+        import contextlib
+        stack = contextlib.ExitStack()
+        for g in self.groups:
+            if g["sync"] is not None:
+                stack.enter_context(g["sync"].no_sync())
+        return stack
+
     def zero_grad(self):
         for g in self.groups:
             g["flat"].zero_grad()
             if g["lp"] is not None:          # pick up in-place parameter edits made between steps
                 K.cast(g["flat"].flat_p, torch.bfloat16, out=g["lp"])
+                g["mirror"].mark_synced()
 
     def step(self):
         self.steps += 1
@@ -102,7 +114,8 @@ class FusedAdamW:
             f = g["flat"]
             K.adamw(f.flat_p, f.flat_g, g["m"], g["v"], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                     g["weight_decay"], self.steps, grad_scale=1.0 / self.world, p_lp=g["lp"])
-        F.bump_weight_epoch()
+        # the AdamW kernel rewrote the bf16 mirrors itself: they stay valid across the epoch bump
+        F.bump_weight_epoch([g["mirror"] for g in self.groups if g["mirror"] is not None])
 
 
 def train_step(model, images, labels, opt: FusedAdamW):

@@ -91,3 +91,77 @@ def test_bucket_boundaries_cover_the_flat_buffer():
     assert sync.buckets[0][0] == 0 and sync.buckets[-1][1] == flat.numel
     for (s0, e0, _), (s1, _, _) in zip(sync.buckets, sync.buckets[1:]):
         assert e0 == s1
+
+
+# ---------------------------------------------------------------------------------------------
+# The overlapped path of DESIGN section 5 as the HIP kernels drive it: gradients accumulated DIRECTLY into
+# the flat buffer + grad_ready(p) calls (no autograd hook) for some parameters, autograd hooks for the
+# others, gradient accumulation over two backward passes (the first under no_sync()), and the fused
+# optimizer's convention finish(average=False) with 1/world folded into its own gradient scale.
+# ---------------------------------------------------------------------------------------------
+_ACC_SHAPES = [(40, 8), (8,), (16, 16), (16,), (3, 5), (7,)]
+
+
+def _acc_micro(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return [[torch.randn(s, generator=g) for s in _ACC_SHAPES] for _ in range(2)]
+
+
+def _accum_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("focused-attention-vit_amd")
+    torch.manual_seed(5)
+    params = [torch.nn.Parameter(torch.randn(s)) for s in _ACC_SHAPES]
+    direct = {0, 2, 5}                                   # "kernel-written" gradients: autograd never sees them
+    flat = pkg.dp.FlatBuffers(params)
+    sync = pkg.dp.GradSync(flat, bucket_mb=0.0001)       # several buckets
+    assert len(sync.buckets) >= 3
+    micro = _acc_micro(rank)
+
+    def backward(coefs):
+        # hooked parameters through autograd (loss = <p, c>  =>  grad = c); direct ones written in place +
+        # grad_ready, interleaved in reverse registration order like a real backward
+        for i in reversed(range(len(params))):
+            if i in direct:
+                params[i].grad.add_(coefs[i])
+                sync.grad_ready(params[i])
+            else:
+                (params[i] * coefs[i]).sum().backward()
+
+    for step in range(2):                                # two optimizer steps: bucket state must reset
+        flat.zero_grad()
+        with sync.no_sync():
+            backward(micro[0])
+            assert not any(sync._launched), "no bucket may launch inside no_sync()"
+        backward(micro[1])                               # last micro-batch: buckets launch as they complete
+        assert all(sync._launched), "every bucket's all-reduce must have been launched by the ready events"
+        sync.finish(average=False)
+    good = [p.grad.clone() for p in params]
+    # accumulating WITHOUT no_sync after the buckets were launched must fail loudly, not corrupt silently
+    err = ""
+    flat.zero_grad()
+    backward(micro[0])
+    try:
+        backward(micro[1])
+    except RuntimeError as e:
+        err = str(e)
+    sync.finish(average=False)
+    if rank == 0:
+        torch.save({"grads": good, "err": err}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_direct_grads_with_accumulation(tmp_path):
+    out = str(tmp_path / "acc.pt")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_accum_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    assert "no_sync" in got["err"]
+    # finish(average=False) leaves SUMS over ranks (1/world is folded into the optimizer's gradient scale)
+    ref = [sum(_acc_micro(r)[0][i] + _acc_micro(r)[1][i] for r in range(2)) for i in range(len(_ACC_SHAPES))]
+    for g, r in zip(got["grads"], ref):
+        assert torch.allclose(g, r, rtol=1e-6, atol=1e-6)

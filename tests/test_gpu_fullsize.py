@@ -1,0 +1,241 @@
+"""GPU parity at the BENCHMARK shapes (BASELINE.json configs[1]: 256 images x 197 tokens = 50,432 token
+rows, D = 384): the kernels bench.py times must be the kernels the parity tests check.
+
+* favit_gemm_grouped_tn (the grouped weight-gradient launch, only taken when the token count is a multiple
+  of 32 and the operands are bf16) against an fp64 dY^T X / column sum, at T = 50,432 and at a small
+  qualifying T;
+* the 256x128-tile kernel's fused epilogues (GELU + saved pre-activation, dGELU, residual, dropout) at
+  p4-sized M with N = 384 / 1536, both B layouts;
+* the whole cfg2 training step at B = 256, forward AND backward, in bf16 and fp32: the two golden cfg2 images
+  tiled 128x (mean cross-entropy => the gradients equal the B = 2 gradients) against the B = 2 HIP gradients
+  element-wise and against the reference's golden gradient norms (models.npz: cfg2/gnorm/*,
+  experiments/mhla_pretrained.py:363-367 is the loop this mirrors).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T_BENCH = 256 * 197
+D = 384
+
+
+@pytest.fixture(scope="module")
+def K(favit):
+    return favit.kernels
+
+
+def _rand(shape, dtype, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen, device=DEV, dtype=torch.float32) * scale).to(dtype)
+
+
+def _block_problems(T, gen, accumulate):
+    """The four dW = dY^T X problems of one transformer block (fc2, fc1, proj, folded qkv)."""
+    shapes = [(D, 4 * D), (4 * D, D), (D, D), (3 * D, D)]          # (N, K) of dW[N, K]
+    probs, refs = [], []
+    for N, Kd in shapes:
+        dy = _rand((T, N), torch.bfloat16, gen, 0.5)
+        x = _rand((T, Kd), torch.bfloat16, gen)
+        if accumulate:
+            dw0 = _rand((N, Kd), torch.float32, gen)
+            db0 = _rand((N,), torch.float32, gen)
+        else:
+            dw0 = torch.full((N, Kd), float("nan"), device=DEV)      # must be overwritten, not added to
+            db0 = torch.zeros(N, device=DEV)                          # a_rowsum is always ADDED (fused db)
+        dw, db = dw0.clone(), db0.clone()
+        probs.append((dy, x, dw, db, accumulate))
+        ref_w = dy.double().t() @ x.double()
+        ref_b = dy.double().sum(0)
+        if accumulate:
+            ref_w, ref_b = ref_w + dw0.double(), ref_b + db0.double()
+        else:
+            ref_b = ref_b + db0.double()
+        refs.append((ref_w, ref_b))
+    return probs, refs
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("T", [512, 2048 + 32, T_BENCH])
+def test_gemm_grouped_tn_block_problems(K, T, accumulate):
+    gen = torch.Generator(device=DEV).manual_seed(T + int(accumulate))
+    probs, refs = _block_problems(T, gen, accumulate)
+    assert K.gemm_grouped_tn(probs), "the grouped launch must accept the block's four problems at T %% 32 == 0"
+    torch.cuda.synchronize()
+    for (dy, x, dw, db, _), (ref_w, ref_b) in zip(probs, refs):
+        assert torch.isfinite(dw).all()
+        assert rel_l2(dw, ref_w) < 2e-5, (tuple(dw.shape), rel_l2(dw, ref_w))
+        assert rel_l2(db, ref_b) < 2e-5, (tuple(dw.shape), rel_l2(db, ref_b))
+
+
+def test_gemm_grouped_tn_declines_what_it_cannot_group(K):
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    T = 197 * 2                                  # not a multiple of 32: callers fall back to single launches
+    probs, _ = _block_problems(T, gen, False)
+    assert K.gemm_grouped_tn(probs) is False
+
+
+def _abi(favit):
+    return favit._abi
+
+
+@pytest.mark.parametrize("bk", [True, False])
+@pytest.mark.parametrize("epi,N,Kd", [("gelu_aux", 1536, 384), ("dgelu", 1536, 384), ("dgelu_drop", 1536, 384),
+                                      ("res_f32", 384, 1536), ("res_f32", 384, 384), ("res_drop_f32", 384, 384),
+                                      ("plain_bf16", 384, 1152), ("plain_bf16", 1152, 384)])
+def test_gemm_p4_epilogues_at_bench_sized_m(K, favit, bk, epi, N, Kd):
+    """M large enough that favit_gemm takes the 256x128-tile kernel for N = 384 (>= 256 tiles), ragged in M."""
+    abi = _abi(favit)
+    M = 86 * 256 + 40
+    gen = torch.Generator(device=DEV).manual_seed(N * 7 + Kd + int(bk))
+    a = _rand((M, Kd), torch.bfloat16, gen)
+    b = _rand((N, Kd) if bk else (Kd, N), torch.bfloat16, gen, 0.05)
+    ldb = Kd if bk else N
+    bias = _rand((N,), torch.float32, gen)
+    base = a.float() @ (b.float().t() if bk else b.float())
+    kw = dict(b_kmajor=bk)
+    if epi == "gelu_aux":
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        pre = torch.empty_like(out)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, bias=bias, act=abi.ACT_GELU, aux_out=pre, ld_aux_out=N, **kw)
+        assert rel_l2(pre.float(), base + bias) < 1e-2
+        assert rel_l2(out.float(), torch.nn.functional.gelu(base + bias)) < 1e-2
+    elif epi in ("dgelu", "dgelu_drop"):
+        pre = _rand((M, N), torch.bfloat16, gen)
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        p, seed = (0.2, 4242) if epi == "dgelu_drop" else (0.0, 0)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, act=abi.ACT_DGELU, aux_in=pre, ld_aux_in=N, dropout_p=p,
+               dropout_seed=seed, **kw)
+        x = pre.float().requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        ref = base * x.grad
+        if p > 0:
+            ref = K.dropout(ref, p, seed)             # the same counter-based mask (index = m * N + n)
+            assert abs((out == 0).float().mean().item() - p) < 0.01
+        assert rel_l2(out.float(), ref) < 1e-2
+    elif epi in ("res_f32", "res_drop_f32"):
+        res = _rand((M, N), torch.float32, gen)
+        out = torch.empty((M, N), dtype=torch.float32, device=DEV)
+        p, seed = (0.1, 99) if epi == "res_drop_f32" else (0.0, 0)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, bias=bias, residual=res, ld_res=N, dropout_p=p, dropout_seed=seed, **kw)
+        y = base + bias
+        if p > 0:
+            y = K.dropout(y, p, seed)
+        assert rel_l2(out, y + res) < 2e-5
+    else:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, bias=bias, **kw)
+        assert rel_l2(out.float(), base + bias) < 1e-2
+
+
+MD = load_golden("models.npz")
+
+
+def _cfg2_model(favit):
+    torch.manual_seed(1234)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384,
+                                                    depth=12, num_heads=6, window_size=7, use_mhla=True)
+    x = torch.randn(2, 3, 224, 224)
+    y = torch.randint(0, 1000, (2,))
+    assert abs(x.double().sum().item() - float(MD["cfg2/x_sum"])) < 1e-6 and torch.equal(y, torch.from_numpy(MD["cfg2/y"]))
+    return m, x, y
+
+
+@pytest.mark.parametrize("mode,tol_elem,tol_gn,tol_logits", [("fp32", 2e-4, 2e-3, 1e-3), ("bf16", 2e-3, 5e-2, 2e-2)])
+def test_full_size_cfg2_forward_backward_matches_golden(favit, K, mode, tol_elem, tol_gn, tol_logits):
+    """B = 256 forward + backward through the fused-optimizer flow of bench.py (flat .grad buffers, direct
+    gradient accumulation, grouped weight-gradient launch) == the B = 2 result == the reference's golden run."""
+    favit.set_compute_dtype(mode)
+    try:
+        m, x, y = _cfg2_model(favit)
+        m.to(DEV).train()                                   # dropout = 0 in this configuration: train == eval math
+        x, y = x.to(DEV), y.to(DEV)
+        # B = 2, plain autograd gradients
+        logits2 = m(x)
+        assert rel_l2(logits2.detach().cpu(), MD["cfg2/logits"]) < tol_logits
+        favit.train.cross_entropy(logits2, y).backward()
+        g2 = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        for p in m.parameters():
+            p.grad = None
+        # B = 256: the pair tiled 128x, flat gradient buffers as in bench.py
+        opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=1e-4), distributed=False)
+        xb, yb = x.repeat(128, 1, 1, 1).contiguous(), y.repeat(128).contiguous()
+        opt.zero_grad()
+        K.GEMM_TRACE = []
+        try:
+            logits = m(xb)
+            loss = favit.train.cross_entropy(logits, yb)
+            loss.backward()
+            torch.cuda.synchronize()
+            keys = {t[3] for t in K.GEMM_TRACE}
+        finally:
+            K.GEMM_TRACE = None
+        if mode == "bf16":
+            assert "bf16_MM_of32_grouped" in keys, f"the grouped weight-gradient kernel did not run: {sorted(keys)}"
+        assert rel_l2(logits[:2].detach().cpu(), MD["cfg2/logits"]) < tol_logits
+        assert rel_l2(logits[254:].detach().cpu(), MD["cfg2/logits"]) < tol_logits
+        assert abs(loss.item() - float(MD["cfg2/loss"])) < tol_logits * abs(float(MD["cfg2/loss"]))
+        worst_e, worst_n = 0.0, 0.0
+        for k, p in m.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+            e = rel_l2(p.grad, g2[k])
+            worst_e = max(worst_e, e)
+            assert e < tol_elem, f"{k}: B=256 vs B=2 gradient rel-L2 {e}"
+            r = float(MD[f"cfg2/gnorm/{k}"])
+            n = abs(p.grad.norm().item() - r) / max(r, 1e-12)
+            worst_n = max(worst_n, n)
+            assert n < tol_gn, f"{k}: gradient norm off the reference's by {n}"
+        print(f"[{mode}] worst element-wise rel-L2 vs B=2: {worst_e:.2e}; worst gradient-norm deviation vs golden: {worst_n:.2e}")
+    finally:
+        favit.set_compute_dtype("fp32")
+        favit.functional.clear_lp_mirrors()
+
+
+def test_fused_optimizer_mirror_sees_external_weight_edits(favit):
+    """Once a FusedAdamW owns a bf16 mirror of the weights, load_state_dict / nn.init / p.copy_ (version
+    counter) and p.data edits + invalidate_weight_cache() (epoch) must reach the next bf16 forward."""
+    favit.set_compute_dtype("bf16")
+    try:
+        torch.manual_seed(0)
+        mk = lambda: favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64,
+                                                                 depth=2, num_heads=4, use_mhla=True).to(DEV)
+        m, other = mk(), mk()
+        x = torch.randn(4, 3, 32, 32, device=DEV)
+        y = torch.randint(0, 10, (4,), device=DEV)
+        opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=1e-2), lr=1e-2, distributed=False)
+        favit.train.train_step(m, x, y, opt)
+        m.eval(), other.eval()
+        with torch.no_grad():
+            want = other(x).float()
+            assert rel_l2(m(x).float(), want) > 0.05              # the two models differ
+            m.load_state_dict(other.state_dict())                 # copy_ into the flat-buffer views
+            assert rel_l2(m(x).float(), want) < 1e-6, "stale bf16 mirror after load_state_dict"
+            torch.nn.init.zeros_(m.head.bias)
+            torch.nn.init.zeros_(other.head.bias)
+            assert rel_l2(m(x).float(), other(x).float()) < 1e-6, "stale bf16 mirror after nn.init"
+            m.head.weight.data.mul_(2.0)                          # invisible to the version counter
+            other.head.weight.data.mul_(2.0)
+            favit.invalidate_weight_cache()
+            assert rel_l2(m(x).float(), other(x).float()) < 1e-6, "stale bf16 mirror after invalidate_weight_cache"
+        # and training continues from the edited weights
+        m.train()
+        l0 = favit.train.train_step(m, x, y, opt).item()
+        l1 = favit.train.train_step(m, x, y, opt).item()
+        assert np.isfinite(l0) and l1 < l0
+    finally:
+        favit.set_compute_dtype("fp32")
+        favit.functional.clear_lp_mirrors()
+
+
+def test_cross_entropy_rejects_bad_arguments(favit, K):
+    logits = torch.randn(4, 10, device=DEV)
+    with pytest.raises(TypeError):
+        K.cross_entropy(logits, torch.zeros(4, dtype=torch.int32, device=DEV))
+    with pytest.raises(TypeError):
+        K.cross_entropy(logits.to(torch.bfloat16), torch.zeros(4, dtype=torch.int64, device=DEV))
+    with pytest.raises(TypeError):
+        K.cross_entropy(logits, torch.zeros(3, dtype=torch.int64, device=DEV))
+    rows, _ = K.cross_entropy(logits, torch.tensor([0, -100, 3, 10], device=DEV), grad_scale=0.25)
+    assert torch.isfinite(rows[0]) and torch.isfinite(rows[2]) and torch.isnan(rows[1]) and torch.isnan(rows[3])
