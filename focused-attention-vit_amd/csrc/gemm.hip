@@ -66,6 +66,7 @@ struct KParams {
   int store_policy;    // cache policy of the epilogue's output stores (store16_policy)
 #ifdef FAVIT_PROBE
   int dbg;     // probe build only (make probe; tools/): 1 = skip epilogue, 2 = skip main loop
+  unsigned long long* probe;   // probe build only: per-wave cycle stamps of the pp kernel (favit_probe_buffer)
 #endif
   const float* scale_a;   // fp8 operands: device dequantisation factors (or null)
   const float* scale_b;
@@ -1009,6 +1010,241 @@ __global__ __launch_bounds__(P4_THREADS, 4) void gemm_fp8_p4_kernel(KParams p) {
 }
 
 // --------------------------------------------------------------------------------------
+// bf16 kernel "pp" (ping-pong): the 256x128 tile and the 64x64 wave tiles of p4, but ONE 512-thread
+// workgroup per CU whose two halves -- waves 0-3 (rows 0-127) and waves 4-7 (rows 128-255); waves w and
+// w+4 share a SIMD -- run one barrier apart: while one half issues its 16 MFMAs of a 32-deep k-step, the
+// other half reads its next fragments from LDS and issues the DMA of a later stage, then they swap.  The
+// matrix pipe of every SIMD always has one wave in its MFMA cluster; LDS-read latency, DMA issue and the
+// barrier are hidden under the partner's cluster instead of relying on occupancy (p4: 4 waves per SIMD,
+// MFMA pipe 19-26 % busy, 40-60 % of wave time parked on s_waitcnt / s_barrier).
+//   stage  = 64 k-values: A image [256 rows][128 B] + B image ([128 rows][128 B] k-major, or [64 k][256 B]
+//            mn-major), 48 KiB, the same swizzled images and 1-KiB DMA pieces as the 128x128 DMA kernel;
+//            three stages (144 KiB): stage s+2 is fetched while stage s is consumed;
+//   reads  = inline-asm ds_read_b128 / ds_read_b64_tr_b16 + ONE explicit lgkmcnt(0) after the barrier, so
+//            the compiler's LDS-DMA alias wait (vmcnt(0) before a read) can never drain the prefetch;
+//   barrier bookkeeping (B(n) = n-th hardware barrier; X / Y = barrier before / after a cluster):
+//            half 0 runs R(s,0) X C(s,0) Y R(s,1) X C(s,1) Y ..., half 1 the same one barrier later.
+//            RAW: every wave waits (counted vmcnt) for its own pieces of stage s+1 before X(s,1); the first
+//            read of stage s+1 (half 0's R(s+1,0)) comes after B(4s+4), which both X(s,1) precede.
+//            WAR: stage s+2 overwrites stage s-1, last read in half 1's R(s-1,1), complete before its
+//            Y(s-1,1) = B(4s+1); half 0 therefore issues the DMA in R(s,1) (after B(4s+2)), half 1 in
+//            R(s,0) (after B(4s+1)).
+// The epilogue is p4's wave-private one and starts without a barrier: a wave's scratch lies in a stage
+// buffer that no wave reads any more (the two that do not hold the last stage).
+// --------------------------------------------------------------------------------------
+constexpr int PP_THREADS = 768;                     // 8 MFMA waves (two ping-pong halves) + 4 loader waves
+constexpr int PP_A_BYTES = 256 * 128;                 // 32 KiB
+constexpr int PP_B_BYTES = 128 * 128;                 // 16 KiB
+constexpr int PP_STAGE = PP_A_BYTES + PP_B_BYTES;     // 48 KiB
+constexpr int PP_LDS = 3 * PP_STAGE;                  // 147456
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((address_space(3))) const char* lds_cptr_t;
+
+// the four k-major fragments of rows r0 + 16 i (r0 a multiple of 16), k-substep ks of a BK = 64 image
+__device__ __forceinline__ void pp_kread4(const char* lds, int r0, int ks, int lane, u32x4_t (&f)[4]) {
+  const int row = r0 + (lane & 15), kc = ks * 4 + (lane >> 4);
+  const unsigned addr = (unsigned)(uintptr_t)(lds_cptr_t)(lds + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+  asm volatile("ds_read_b128 %0, %1" : "=v"(f[0]) : "v"(addr) : "memory");
+  asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(f[1]) : "v"(addr) : "memory");
+  asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(f[2]) : "v"(addr) : "memory");
+  asm volatile("ds_read_b128 %0, %1 offset:6144" : "=v"(f[3]) : "v"(addr) : "memory");
+}
+
+__device__ __forceinline__ void pp_fence_kk(u32x4_t (&a)[4], u32x4_t (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+               :
+               : "memory");
+}
+
+__device__ __forceinline__ void pp_fence_km(u32x4_t (&a)[4], u32x2_t (&l)[4], u32x2_t (&h)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]),
+                 "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3])
+               :
+               : "memory");
+}
+
+template <bool BKM, typename OutT>
+__global__ __launch_bounds__(PP_THREADS) void gemm_bf16_pp_kernel(KParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long m0 = (long)(tile / p.tiles_n) * P4_BM;
+  const long n0 = (long)(tile % p.tiles_n) * BN;
+  const int nk = (int)(p.K / BK16);                   // >= 2 (host)
+  const int nb = 4 * nk;                              // barrier intervals of the main loop
+
+  if (wave >= 8) {
+    // ---- loader wave l: A pieces 8l .. 8l+7 and B pieces 4l .. 4l+3 of every stage, three per interval ----
+    const int l = wave - 8;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B);
+    const bf16_t* sa[8];
+    const bf16_t* sb[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sa[j] = glds_src<true>(A, p.lda, m0, p.M, 0, l * 8 + j, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sb[j] = glds_src<BKM>(Bm, p.ldb, n0, p.N, 0, l * 4 + j, lane);
+    const long b_step = BKM ? BK16 : (long)BK16 * p.ldb;
+    // group g (0..3) of the stage that goes to ring slot `slot`: A pieces 2g, 2g+1 and B piece g of this wave
+    auto issue_group = [&](int slot, int g) {
+      char* st = smem + slot * PP_STAGE;
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) {
+        if (gg == g) {
+          __builtin_amdgcn_global_load_lds((gptr_t)sa[2 * gg], (lptr_t)(st + (l * 8 + 2 * gg) * 1024), 16, 0, 0);
+          sa[2 * gg] += BK16;
+          __builtin_amdgcn_global_load_lds((gptr_t)sa[2 * gg + 1], (lptr_t)(st + (l * 8 + 2 * gg + 1) * 1024), 16, 0, 0);
+          sa[2 * gg + 1] += BK16;
+          __builtin_amdgcn_global_load_lds((gptr_t)sb[gg], (lptr_t)(st + PP_A_BYTES + (l * 4 + gg) * 1024), 16, 0, 0);
+          sb[gg] += b_step;
+        }
+      }
+    };
+    // intervals -7 .. -1 of the schedule below: stage 0 whole, three groups of stage 1
+#pragma unroll
+    for (int g = 0; g < 4; ++g) issue_group(0, g);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) issue_group(1, g);
+    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // own pieces of stage 0 landed
+    __builtin_amdgcn_s_barrier();                     // B(0)
+    // interval n (between B(n) and B(n+1)): group (n+7)%4 of stage t = (n+7)/4, whose slot is free once B(4t-7)
+    // has been passed; before B(4t') the pieces of stage t' must have landed.
+    int t = 1, g = 3, slot = 1;
+    for (int n = 0; n < nb; ++n) {
+#ifdef FAVIT_PROBE
+      if (t < nk && !(p.dbg & 4)) issue_group(slot, g);          // dbg 4: no DMA in the loop (timing only)
+#else
+      if (t < nk) issue_group(slot, g);
+#endif
+      if ((n & 3) == 3) {                             // next barrier is B(n+1) = B(4t'), t' = (n+1)/4: stage t' must have landed
+        const int tp = (n + 1) >> 2;
+        if (tp < nk) {
+          // younger than stage t' at this point: the three groups of stage t'+1 issued in intervals n-2 .. n
+          if (tp + 1 < nk) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      __builtin_amdgcn_s_barrier();                   // B(n+1)
+      if (++g == 4) { g = 0; ++t; slot = slot == 2 ? 0 : slot + 1; }
+    }
+    return;
+  }
+
+  // ---- consumer waves: two ping-pong halves of four ----
+  const int half = wave >> 2;                         // waves w and w + 4 share a SIMD
+  const int wr = half * 2 + ((wave >> 1) & 1), wc = wave & 1;
+  OutT* C = reinterpret_cast<OutT*>(p.C);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  __builtin_amdgcn_s_barrier();                       // B(0): stage 0 landed
+  if (half == 1) __builtin_amdgcn_s_barrier();        // half 1 runs one barrier behind half 0
+
+#ifdef FAVIT_PROBE
+  // in-kernel stamps (probe build): cycles per wave spent in [read section + X wait], [fence + MFMA issue], [Y wait]
+  unsigned long long pt_r = 0, pt_c = 0, pt_y = 0, pt0 = 0, pt1 = 0, pt2 = 0;
+#define PP_STAMP(x) do { if (p.probe) { x = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x) :: "memory"); } } while (0)
+  PP_STAMP(pt0);
+  const unsigned long long pt_begin = pt0;
+#else
+#define PP_STAMP(x)
+#endif
+  int cur = 0;                                        // ring slot of stage s
+  for (int s = 0; s < nk; ++s) {
+    const char* la = smem + cur * PP_STAGE;
+    const char* lb = la + PP_A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4_t af[4], bk4[4];
+      u32x2_t bl[4], bh[4];
+#ifdef FAVIT_PROBE
+      if (p.dbg & 8) {                                // dbg 8: no LDS fragment reads (timing only)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { af[i] = (u32x4_t){1u, 2u, 3u, 4u}; bk4[i] = af[i]; bl[i] = (u32x2_t){1u, 2u}; bh[i] = bl[i]; }
+      } else
+#endif
+      {
+      pp_kread4(la, wr * 64, ks, lane, af);
+      if constexpr (BKM) {
+        pp_kread4(lb, wc * 64, ks, lane, bk4);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tr_read_pair(lb, wc * 64 + j * 16, ks, lane, bl[j], bh[j]);
+      }
+      }
+      __builtin_amdgcn_s_barrier();                   // X(s, ks)
+      bf16x8 bfr[4];
+      if constexpr (BKM) {
+        pp_fence_kk(af, bk4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = __builtin_bit_cast(bf16x8, bk4[j]);
+      } else {
+        pp_fence_km(af, bl, bh);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = tr_pack(bl[j], bh[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef FAVIT_PROBE
+      PP_STAMP(pt1);
+      pt_r += pt1 - pt0;
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef FAVIT_PROBE
+      PP_STAMP(pt2);
+      pt_c += pt2 - pt1;
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      // Y(s, ks); half 1 omits its very last one: with its extra barrier up front every wave executes 4 nk + 1
+      if (!(half == 1 && s == nk - 1 && ks == 1)) __builtin_amdgcn_s_barrier();
+#ifdef FAVIT_PROBE
+      PP_STAMP(pt0);
+      pt_y += pt0 - pt2;
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  // `cur` is now the slot after the last stage's; the last stage sits in slot (cur + 2) % 3 and may still be
+  // read by half 1.  Wave-private epilogue scratch lives in the two other slots (4 waves each).
+  const int free0 = cur, free1 = cur == 2 ? 0 : cur + 1;
+  float* wl = reinterpret_cast<float*>(smem + (half ? free1 : free0) * PP_STAGE + (wave & 3) * WEPI_BYTES);
+  wave_epilogue<bf16_t, OutT>(p, acc, C, m0 + wr * 64, n0 + wc * 64, lane, wl, true, p.alpha);
+#ifdef FAVIT_PROBE
+  if (p.probe && lane == 0) {          // [block][wave][5]: read, cluster, y-wait, loop total, whole kernel
+    unsigned long long pt_end;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_STAMP(pt_end);
+    unsigned long long* o = p.probe + ((size_t)blockIdx.x * 8 + wave) * 5;
+    o[0] = pt_r; o[1] = pt_c; o[2] = pt_y; o[3] = pt0 - pt_begin; o[4] = pt_end - pt_begin;
+  }
+#endif
+}
+
+template <typename Kn>
+int launch_pp(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
+  favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), PP_LDS);
+  hipLaunchKernelGGL(kernel, grid, dim3(PP_THREADS), PP_LDS, st, kp);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+// --------------------------------------------------------------------------------------
 // bf16 kernel "p7": 256x256 tile, SIXTEEN waves (4x4, 64x64 each), BK = 32, three 32-KiB stages
 // (96 KiB -> one 1024-thread workgroup per CU: the same 4 waves/SIMD and 128 VGPRs as two p4
 // workgroups).  The operand stream per flop drops by a third (L2->LDS intensity 128 vs 85 flop/B),
@@ -1423,7 +1659,7 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 // same result; the work-skipping probe switch (FAVIT_GEMM_DBG) exists only in the `make probe` build.
 struct GemmKnobs {
   int dbg, store_policy;
-  bool force128, no_p4, no_p7, no_s64;
+  bool force128, no_p4, no_p7, no_s64, no_pp;
   GemmKnobs() {
     const char* e;
 #ifdef FAVIT_PROBE
@@ -1436,6 +1672,7 @@ struct GemmKnobs {
     no_p4 = getenv("FAVIT_GEMM_NO_P4") != nullptr;
     no_p7 = getenv("FAVIT_GEMM_NO_P7") != nullptr;
     no_s64 = getenv("FAVIT_GEMM_NO_S64") != nullptr;
+    no_pp = getenv("FAVIT_GEMM_NO_PP") != nullptr;
   }
 };
 static const GemmKnobs& knobs() {
@@ -1443,7 +1680,16 @@ static const GemmKnobs& knobs() {
   return k;
 }
 
+#ifdef FAVIT_PROBE
+unsigned long long* g_probe_buffer = nullptr;
+#endif
+
 }  // namespace
+
+#ifdef FAVIT_PROBE
+// probe build only (not declared in include/favit.h): device buffer of >= grid * 8 * 5 uint64 for the pp stamps
+extern "C" void favit_probe_buffer(void* buf) { g_probe_buffer = reinterpret_cast<unsigned long long*>(buf); }
+#endif
 
 extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   if (!g || !g->A || !g->B || !g->C) return FAVIT_ERR_INVALID;
@@ -1530,6 +1776,7 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.scale_b = fp8 ? g->scale_b : nullptr;
 #ifdef FAVIT_PROBE
   kp.dbg = knobs().dbg;
+  kp.probe = g_probe_buffer;
 #endif
   // epilogue outputs / residual / aux reads are touched once: non-temporal keeps them from evicting
   // the operand panels the co-resident workgroups share in L2 (fc2: 140 -> 114 us)
@@ -1601,6 +1848,23 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
     dim3 grid7((unsigned)k7.ntiles, 1u, 1u);
     if (g->out_dtype == FAVIT_BF16) return launch_p7(gemm_bf16_p7_kernel<bf16_t>, k7, grid7, st);
     return launch_p7(gemm_bf16_p7_kernel<float>, k7, grid7, st);
+  }
+  // ping-pong kernel: single-pass problems with a k-major A and a LONG reduction (K >= 2048: the ViT-Base
+  // input-gradient GEMMs, large squares) that the 256x256 kernel cannot take (mn-major B, or N % 256 != 0).
+  // Measured (tools/gemm_bench.py, tools/pp_probe.py): 8192^3 1053-1081 TF against 962 TF for p4 on the same
+  // device; a tie at K = 1536 and a loss at K = 384, where one workgroup per CU leaves prologue and epilogue
+  // uncovered -- so the training step's K <= 1536 shapes stay on p4.  FAVIT_GEMM_PP=1 forces it (tests).
+  const bool pp_shape = (g->K >= 2048 && t4 >= 256) || getenv("FAVIT_GEMM_PP") != nullptr;   // read per call: tests toggle it
+  if (glds_ok && !force128 && !knobs().no_pp && pp_shape && splits == 1 && !atomic && batch == 1 && g->a_kmajor &&
+      !g->a_rowsum && g->M >= 256 && (g->K % BK16) == 0 && g->K >= 2 * BK16) {
+    dim3 gridp((unsigned)t4, 1u, 1u);
+    kp.ntiles = (int)t4;
+    if (g->out_dtype == FAVIT_BF16) {
+      if (g->b_kmajor) return launch_pp(gemm_bf16_pp_kernel<true, bf16_t>, kp, gridp, st);
+      return launch_pp(gemm_bf16_pp_kernel<false, bf16_t>, kp, gridp, st);
+    }
+    if (g->b_kmajor) return launch_pp(gemm_bf16_pp_kernel<true, float>, kp, gridp, st);
+    return launch_pp(gemm_bf16_pp_kernel<false, float>, kp, gridp, st);
   }
   if (glds_ok && !force128 && !no_p4 && (g->K % P4_BK) == 0 && (kps % P4_BK) == 0 &&
       ((splits == 1 && g->M >= 1024 && t4 * batch >= 256) || (xcd_split && splits > 1))) {
@@ -1723,6 +1987,7 @@ extern "C" int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void
     kp.store_policy = 0;
 #ifdef FAVIT_PROBE
     kp.dbg = 0;
+    kp.probe = nullptr;
 #endif
     gp.tile_off[i] = off;
     off += kp.ntiles;

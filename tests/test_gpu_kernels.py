@@ -447,6 +447,45 @@ def test_gemm_256x256_tile_kernel(K, bk, out_dtype, epi):
     assert rel_l2(out.float(), ref) < (1e-2 if out_dtype == torch.bfloat16 else 2e-5)
 
 
+@pytest.mark.parametrize("bk", [True, False])
+@pytest.mark.parametrize("M,N,Kd,forced", [(8192 + 40, 1024 + 128, 2048, False), (2048 + 40, 384, 512, True),
+                                           (1024, 200, 128, True), (300, 128, 1536, True)])
+@pytest.mark.parametrize("out_dtype,epi", [(torch.bfloat16, "gelu"), (torch.bfloat16, "dgelu"), (torch.float32, "res")])
+def test_gemm_ping_pong_kernel(K, bk, M, N, Kd, forced, out_dtype, epi, monkeypatch):
+    """The 12-wave ping-pong kernel (two MFMA halves one barrier apart + four loader waves): taken by itself for
+    K >= 2048 problems the 256x256 kernel cannot serve, forced (FAVIT_GEMM_PP, read per call) on small / ragged /
+    short-K shapes (2 .. 24 stages, ragged M and N, both B layouts, fused epilogues)."""
+    if forced:
+        monkeypatch.setenv("FAVIT_GEMM_PP", "1")
+    if not bk and N % 8:
+        pytest.skip("mn-major DMA images need N % 8 == 0")
+    g = torch.Generator(device=DEV).manual_seed(M + N + Kd)
+    a = _rand((M, Kd), torch.bfloat16, g)
+    b = _rand((N, Kd) if bk else (Kd, N), torch.bfloat16, g)
+    bias = _rand((N,), torch.float32, g)
+    out = torch.empty((M, N), dtype=out_dtype, device=DEV)
+    ref = a.float() @ (b.float().t() if bk else b.float())
+    kw = dict(b_kmajor=bk)
+    ldb = Kd if bk else N
+    if epi == "gelu":
+        pre = torch.empty_like(out)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, bias=bias, act=_abi().ACT_GELU, aux_out=pre, ld_aux_out=N, **kw)
+        ref = ref + bias
+        assert rel_l2(pre.float(), ref) < 1e-2
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == "dgelu":
+        pre = _rand((M, N), torch.bfloat16, g)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, act=_abi().ACT_DGELU, aux_in=pre, ld_aux_in=N, **kw)
+        x = pre.float().requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        ref = ref * x.grad
+    else:
+        res = _rand((M, N), torch.float32, g)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, bias=bias, residual=res, ld_res=N, **kw)
+        ref = ref + bias + res
+    assert rel_l2(out.float(), ref) < (1e-2 if out_dtype == torch.bfloat16 else 2e-5)
+
+
 # ---------------------------------------------------------------------------------------------
 # Seeded random sweeps: every dispatch branch of favit_gemm (register-staged / DMA 128x128 / 256x128 /
 # 256x256 / split-K / fp32) is reached by some shape below; ragged sizes and odd leading dimensions.
