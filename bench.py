@@ -1,15 +1,25 @@
 #!/usr/bin/env python3
-"""Headline benchmark: training images/sec of ViT-MHLA-Small 224x224 / patch16 (197 tokens,
-window 7) -- BASELINE.json configs[1] -- on N MI355X, one process per GPU (RCCL over xGMI).
+"""Training-throughput benchmark (images/sec, fwd + loss + bwd + all-reduce + AdamW) on N MI355X, one
+process per GPU (RCCL over xGMI).  The default is the headline, BASELINE.json configs[1]:
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5                      # ViT-MHLA-Small 224/p16, 256 img/GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = zero_grad -> forward -> cross-entropy -> backward -> gradient all-reduce -> AdamW on one
-synthetic batch (images already resident in HBM).  Rank 0 prints ONE JSON line.
+--config selects the other BASELINE.json configurations:
+    cfg1  ViT-Tiny (models/vit.py, dense attention) 32x32 patch4, 64 img/GPU, step replayed from a HIP graph;
+          CPU baseline at the exact B = 64
+    cfg2  ViT-MHLA-Small 224x224 patch16, 197 tokens, 256 img/GPU            (headline, default)
+    cfg3  SPPP+MHLA Small 224x224, 16 superpixels -> 17 tokens, 128 img/GPU, step replayed from a HIP graph
+    cfg4  ViT-MHLA-Base 384x384 patch16, 577 tokens, 64 img/GPU, --dtype bf16 | fp8
+
+A step = zero_grad -> forward -> cross-entropy -> backward -> gradient all-reduce -> AdamW on one synthetic
+batch already resident in HBM.  Rank 0 prints ONE JSON line.  Per-launch GEMM timing (HIP events on the launch
+stream) runs in extra, un-timed steps AFTER the timed region.
 """
 import argparse
+import glob
+import hashlib
 import importlib
 import json
 import os
@@ -19,6 +29,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -26,13 +37,64 @@ HBM_PEAK_GBPS = 8000.0
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MFMA_PEAK_TFLOPS = 157.3
 FP8_DENSE_PEAK_TFLOPS = 5000.0
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
 
 
-def flops_per_image_train(L=197, D=384, depth=12, hd=64, W=7, N=196, P=16, C=3, classes=1000):
-    """BASELINE.md section 3 / SURVEY 8(d): F_train = 3 * F_fwd."""
-    blk = L * (24 * D * D + 4 * D * hd + 4 * W * D)
+def flops_per_image_train(L, D, depth, hd, W, N, P, C, classes, dense=False):
+    """BASELINE.md section 3 / SURVEY 8(d): F_train = 3 * F_fwd (1 MAC = 2 FLOP)."""
+    blk = L * (24 * D * D + 4 * L * D) if dense else L * (24 * D * D + 4 * D * hd + 4 * W * D)
     fwd = depth * blk + 2 * N * P * P * C * D + 2 * D * classes
     return 3 * fwd
+
+
+def synthetic_label_maps(n_maps, img, regions, seed):
+    """Voronoi label maps (input data of the SPPP configurations: SLIC itself is outside the path).  Jittered
+    grid seeds so that every region dominates at least one 16x16 patch."""
+    rs = np.random.RandomState(seed)
+    side = int(round(regions ** 0.5))
+    yy, xx = np.mgrid[0:img, 0:img]
+    out = []
+    for _ in range(n_maps):
+        cell = img / side
+        cy, cx = np.mgrid[0:side, 0:side]
+        py = (cy.ravel() + 0.5 + rs.uniform(-0.2, 0.2, side * side)) * cell
+        px = (cx.ravel() + 0.5 + rs.uniform(-0.2, 0.2, side * side)) * cell
+        d = (yy[None] - py[:, None, None]) ** 2 + (xx[None] - px[:, None, None]) ** 2
+        out.append(d.argmin(0).astype(np.int64))
+    return np.stack(out)
+
+
+CONFIGS = {
+    "cfg1": dict(name="ViT-Tiny (D192/12L/3H, dense attention) 32x32 patch4, 65 tokens", batch=64, img=32, classes=10,
+                 flops=dict(L=65, D=192, depth=12, hd=64, W=0, N=64, P=4, C=3, classes=10, dense=True),
+                 metric="images/sec (train fwd+bwd) ViT-Tiny 32/p4", cpu_batch=64, cpu_steps=24),
+    "cfg2": dict(name="ViT-MHLA-Small (D384/12L/6H, window 7) 224x224 patch16, 197 tokens", batch=256, img=224,
+                 classes=1000, flops=dict(L=197, D=384, depth=12, hd=64, W=7, N=196, P=16, C=3, classes=1000),
+                 metric="images/sec (train fwd+bwd) ViT-MHLA 224/p16", cpu_batch=16, cpu_steps=24),
+    "cfg3": dict(name="SPPP+MHLA Small (D384/12L/6H, 16 superpixels -> 17 tokens, window 7) 224x224 patch16, "
+                      "HIP-graph replayed step", batch=128, img=224, classes=1000,
+                 flops=dict(L=17, D=384, depth=12, hd=64, W=7, N=196, P=16, C=3, classes=1000),
+                 metric="images/sec (train fwd+bwd) SPPP+MHLA 224/p16", cpu_batch=16, cpu_steps=12),
+    "cfg4": dict(name="ViT-MHLA-Base (D768/12L/12H, window 7) 384x384 patch16, 577 tokens", batch=64, img=384,
+                 classes=1000, flops=dict(L=577, D=768, depth=12, hd=64, W=7, N=576, P=16, C=3, classes=1000),
+                 metric="images/sec (train fwd+bwd) ViT-MHLA-Base 384/p16", cpu_batch=2, cpu_steps=4),
+}
+
+
+def build_model(pkg, cfg, dev):
+    M = pkg.models
+    if cfg == "cfg1":
+        return M.vit.VisionTransformer(img_size=32, patch_size=4, num_classes=10, embed_dim=192, depth=12, num_heads=3).to(dev)
+    if cfg == "cfg2":
+        return M.vit_mhla.VisionTransformerMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12,
+                                                num_heads=6, window_size=7, use_mhla=True, dropout=0.0,
+                                                attn_dropout=0.0, embed_dropout=0.0).to(dev)
+    if cfg == "cfg3":
+        return M.sppp_mhla.SPPPViTMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12, num_heads=6,
+                                       num_superpixels=16, pooling_type="mean", window_size=7, use_mhla=True).to(dev)
+    return M.vit_mhla.VisionTransformerMHLA(img_size=384, patch_size=16, num_classes=1000, embed_dim=768, depth=12,
+                                            num_heads=12, window_size=7, use_mhla=True, dropout=0.0, attn_dropout=0.0,
+                                            embed_dropout=0.0).to(dev)
 
 
 def host_cores():
@@ -56,23 +118,42 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def cpu_baseline(pkg, model, batch=16, steps=24):
-    """The CPU oracle (oracle/favit_oracle.py, a port of the reference's PyTorch-CPU path) timed on
-    this box's host cores: same model config, B=16, 1 warm-up + `steps` timed fwd+bwd steps."""
+def csrc_sha16():
+    """Fingerprint of the kernel sources: a PMC profile is only valid for the kernels it was taken on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "focused-attention-vit_amd", "csrc", "*"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(cfg, model, segs_np):
+    """The CPU oracle (oracle/favit_oracle.py, a port of the reference's PyTorch-CPU path) timed on this box's
+    host cores: same model configuration and weights, fp32, 1 warm-up + N timed fwd+bwd steps (bounded sample)."""
     from oracle import favit_oracle as O
+    c = CONFIGS[cfg]
     cores = host_cores()
     torch.set_num_threads(cores)
     log(f"cpu_baseline on {cores} host cores")
+    batch, steps = c["cpu_batch"], c["cpu_steps"]
     sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(1234)
-    x = torch.randn(batch, 3, 224, 224, generator=g)
-    y = torch.randint(0, 1000, (batch,), generator=g)
+    x = torch.randn(batch, 3, c["img"], c["img"], generator=g)
+    y = torch.randint(0, c["classes"], (batch,), generator=g)
+
+    def fwd():
+        if cfg == "cfg1":
+            return O.vit_forward(x, sd, 4, 3)
+        if cfg == "cfg2":
+            return O.vit_mhla_forward(x, sd, 16, 6, 7, True)
+        if cfg == "cfg3":
+            return O.sppp_vit_mhla_forward(x, segs_np[:batch], sd, 16, 6, 7, True)
+        return O.vit_mhla_forward(x, sd, 16, 12, 7, True)
 
     def step():
         for v in sd.values():
             v.grad = None
-        loss = O.cross_entropy(O.vit_mhla_forward(x, sd, 16, 6, 7, True), y)
-        loss.backward()
+        O.cross_entropy(fwd(), y).backward()
 
     step()
     t0 = time.perf_counter()
@@ -80,7 +161,7 @@ def cpu_baseline(pkg, model, batch=16, steps=24):
         step()
     dt = time.perf_counter() - t0
     return {"value": round(batch * steps / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"ViT-MHLA-Small 224/p16 fwd+bwd fp32, batch {batch}, 1 warm-up + {steps} timed steps "
+            "sample": f"{c['name'].split(' (')[0]} fwd+bwd fp32, batch {batch}, 1 warm-up + {steps} timed steps "
                       f"({dt:.1f} s of CPU work)"}
 
 
@@ -89,15 +170,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE.json configs[1]: 256)")
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS), help="BASELINE.json configuration (cfg2 = headline)")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the configuration's own)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"],
-                    help="bf16 = BASELINE.json configs[1] (the headline); fp8 = the configs[3] GEMM path, informational")
+                    help="bf16 = the headline; fp8 = the BASELINE.json configs[3] GEMM path (cfg4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=os.environ.get("FAVIT_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
     ap.add_argument("--no-gemm-trace", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="cfg1 / cfg3: eager launches instead of the replayed HIP graph")
     ap.add_argument("--side-stream", action="store_true", help="run weight-gradient GEMMs on a second HIP stream")
     args = ap.parse_args()
+    c = CONFIGS[args.config]
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this host driver (before any HIP call)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,7 +192,6 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -121,46 +204,49 @@ def main():
     pkg.set_side_stream(args.side_stream)
 
     torch.manual_seed(1234)
-    model = pkg.models.vit_mhla.VisionTransformerMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384,
-                                                      depth=12, num_heads=6, window_size=7, use_mhla=True,
-                                                      dropout=0.0, attn_dropout=0.0, embed_dropout=0.0).to(dev)
+    model = build_model(pkg, args.config, dev)
     model.train()
-    B = args.batch
+    B = args.batch or c["batch"]
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    images = torch.randn(B, 3, 224, 224, device=dev, generator=g)
-    labels = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    images = torch.randn(B, 3, c["img"], c["img"], device=dev, generator=g)
+    labels = torch.randint(0, c["classes"], (B,), device=dev, generator=g)
+    segs_np = None
+    if args.config == "cfg3":
+        segs_np = synthetic_label_maps(8, 224, 16, seed=100 + rank)
+        segs = torch.from_numpy(np.stack([segs_np[i % 8] for i in range(B)])).to(dev)
+        model.segmentation.set_label_maps(segs)
+        segs_np = np.stack([segs_np[i % 8] for i in range(max(B, c["cpu_batch"]))])
     opt = pkg.train.FusedAdamW(pkg.train.param_groups(model, lr=1e-4), lr=1e-4, weight_decay=0.05)
+    graphed = args.config in ("cfg1", "cfg3") and not args.no_graph
+    if graphed:
+        # hundreds of launches of a few microseconds per step: the Python launch path, not the GPU, would set the
+        # step time (cfg3: 17 tokens per image; cfg1: 65 tokens of width 192)
+        if args.config == "cfg3":
+            model.assume_num_tokens = 16
+        gstep = pkg.train.GraphedStep(model, opt, images, labels)
+        step = lambda: gstep(images, labels)
+    else:
+        step = lambda: pkg.train.train_step(model, images, labels, opt)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"rank {rank}/{world}: model built, warming up")
+    log(f"rank {rank}/{world}: {args.config} model built, warming up")
     for _ in range(args.warmup):
-        pkg.train.train_step(model, images, labels, opt)
+        step()
     sync()
     log("warm-up done, timing")
 
-    trace = None if args.no_gemm_trace else []
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    e_begin, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    traced_steps = 0
+    e_begin.record()
     for s in range(args.steps):
-        # HIP events around every favit_gemm launch cost ~5 % of a step: trace every 10th timed step
-        K.GEMM_TRACE = trace if (trace is not None and s % 10 == 0) else None
-        traced_steps += int(K.GEMM_TRACE is not None)
-        ev[s][0].record()
-        opt.zero_grad()
-        loss = pkg.train.cross_entropy(model(images), labels)
-        loss.backward()
-        ev[s][1].record()
-        opt.step()
-        ev[s][2].record()
+        loss = step()
+    e_end.record()
     sync()
     dt = time.perf_counter() - t0
-    K.GEMM_TRACE = None
     log(f"timed region done: {1e3 * dt / args.steps:.2f} ms/step")
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -169,22 +255,44 @@ def main():
     dt = float(t.item())
     loss_val = float(loss.item())
 
+    # per-launch GEMM timing: two extra EAGER steps after the timed region (events cannot be captured in a graph).
+    # Every rank runs them (the all-reduce inside opt.step() is collective); only rank 0 records events.
+    trace, traced_steps, opt_ms = None, 0, None
+    if not args.no_gemm_trace:
+        trace = [] if rank == 0 else None
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        for s in range(2):
+            K.GEMM_TRACE = trace
+            opt.zero_grad()
+            e[0].record()
+            lo = pkg.train.cross_entropy(model(images), labels)
+            lo.backward()
+            K.GEMM_TRACE = None
+            e[1].record()
+            opt.step()
+            e[2].record()
+            traced_steps += 1
+        torch.cuda.synchronize()
+        opt_ms = e[1].elapsed_time(e[2])
+    if world > 1:
+        dist.barrier()
+
     if rank == 0:
         n_img = world * B * args.steps
-        fb = sum(a.elapsed_time(b) for a, b, _ in ev) / args.steps
-        op_ms = sum(b.elapsed_time(c) for _, b, c in ev) / args.steps
         out = {
-            "metric": "images/sec (train fwd+bwd) ViT-MHLA 224/p16",
+            "metric": c["metric"],
             "value": round(n_img / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "ViT-MHLA-Small (D384/12L/6H, window 7) 224x224 patch16, 197 tokens, "
-                                   f"{B} images/GPU; step = fwd + cross-entropy + bwd + grad all-reduce + AdamW",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random-init (seed 1234)"},
-            "breakdown_ms": {"fwd_bwd": round(fb, 3), "optimizer_and_allreduce_wait": round(op_ms, 3)},
+            "config": {"workload": f"{c['name']}, {B} images/GPU; step = fwd + cross-entropy + bwd + grad all-reduce + AdamW",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random-init (seed 1234)",
+                       "baseline_config": args.config, "hip_graph": bool(graphed)},
+            "gpu_ms_per_step_events": round(e_begin.elapsed_time(e_end) / args.steps, 3),
             "loss": round(loss_val, 5),
-            "model_tflops_per_s": round(n_img * flops_per_image_train() / dt / 1e12, 2),
+            "model_tflops_per_s": round(n_img * flops_per_image_train(**c["flops"]) / dt / 1e12, 2),
         }
+        if opt_ms is not None:
+            out["optimizer_and_allreduce_wait_ms"] = round(opt_ms, 3)
         if trace:
             fam = {}
             for e0, e1, fl, key, shp in trace:
@@ -197,19 +305,25 @@ def main():
             peak = (BF16_DENSE_PEAK_TFLOPS if dom.startswith("bf16") else
                     FP8_DENSE_PEAK_TFLOPS if dom.startswith("fp8") else F32_MFMA_PEAK_TFLOPS)
             ach = fl / sec / 1e12
-            traffic = None           # HBM bytes per launch from the committed PMC passes (profiles/)
+            # HBM bytes per launch come from committed PMC passes (rocprofv3 cannot run inside this process); they
+            # are only reported while the kernel sources are the ones the profile was taken on.
+            traffic, stale = None, None
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-                    traffic = json.load(f)["families"][dom]["hbm_bytes_per_launch"]
+                with open(TRAFFIC_PROFILE) as f:
+                    prof = json.load(f)
+                if prof.get("config", "cfg2") == args.config and args.dtype == prof.get("dtype", "bf16"):
+                    traffic = prof["families"][dom]["hbm_bytes_per_launch"]
+                    stale = prof.get("csrc_sha16") != csrc_sha16()
             except (OSError, KeyError, ValueError):
                 pass
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": traffic,
                                "kernel": f"gemm_{dom}", "launches": n, "avg_launch_us": round(1e6 * sec / n, 2),
-                               "avg_flops_per_launch": round(fl / n, 1)}
-            if traffic:
-                # the same launches seen from the memory side (these K<=1536 GEMMs sit near the
-                # 312 flop/B machine balance): measured HBM bytes / launch time vs the 8 TB/s peak
+                               "avg_flops_per_launch": round(fl / n, 1),
+                               "measured": "HIP events around every launch of this kernel family in 2 un-timed steps after the timed region"}
+            if traffic is not None:
+                out["roofline"]["traffic_source"] = os.path.relpath(TRAFFIC_PROFILE, ROOT)
+                out["roofline"]["traffic_stale"] = bool(stale)      # true: csrc/ changed since the PMC passes were taken
                 gbps = traffic / (sec / n) / 1e9
                 out["roofline"]["hbm_view"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                "frac": round(gbps / HBM_PEAK_GBPS, 4)}
@@ -218,9 +332,8 @@ def main():
                                         "tflops": round(v[1] / v[0] / 1e12, 1), "launches_per_step": v[2] // traced_steps}
                                     for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
             out["gemm_share_of_step"] = round(tot / traced_steps / (dt / args.steps), 3)
-            out["gemm_traced_steps"] = traced_steps
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, model)
+            out["cpu_baseline"] = cpu_baseline(args.config, model, segs_np)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

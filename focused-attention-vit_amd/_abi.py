@@ -37,6 +37,18 @@ class GemmDesc(C.Structure):
     ]
 
 
+class SdpaDesc(C.Structure):
+    """Mirror of favit_sdpa_t (include/favit.h)."""
+    _fields_ = [
+        ("q", vp), ("k", vp), ("v", vp), ("o", vp), ("lse", vp), ("dout", vp), ("dq", vp), ("dk", vp), ("dv", vp),
+        ("delta", vp), ("mask", vp), ("m_sb", i64), ("m_sq", i64),
+        ("q_str", i64 * 3), ("k_str", i64 * 3), ("v_str", i64 * 3), ("o_str", i64 * 3), ("do_str", i64 * 3),
+        ("dq_str", i64 * 3), ("dk_str", i64 * 3), ("dv_str", i64 * 3),
+        ("B", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("hd", i32), ("dtype", i32),
+        ("scale", f32), ("dropout_p", f32), ("seed", u64),
+    ]
+
+
 _SIGS = {
     "favit_abi_version": ([], C.c_int),
     "favit_strerror": ([C.c_int], C.c_char_p),
@@ -54,6 +66,8 @@ _SIGS = {
     "favit_mhla_fold_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], C.c_int),
     "favit_mhla_attn_fwd": ([vp, vp, vp, i32, i32, i32, i32, i32, C.c_int, f32, u64, vp], C.c_int),
     "favit_mhla_attn_bwd": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, C.c_int, f32, u64, vp], C.c_int),
+    "favit_sdpa_fwd": ([C.POINTER(SdpaDesc), vp], C.c_int),
+    "favit_sdpa_bwd": ([C.POINTER(SdpaDesc), vp], C.c_int),
     "favit_softmax_fwd": ([vp, vp, vp, C.c_int, vp, i64, i64, i32, i64, i32, i32, f32, u64, vp], C.c_int),
     "favit_softmax_bwd": ([vp, C.c_int, vp, vp, C.c_int, i64, i32, i32, f32, u64, vp], C.c_int),
     "favit_patchify_fwd": ([vp, vp, C.c_int, i32, i32, i32, i32, vp], C.c_int),

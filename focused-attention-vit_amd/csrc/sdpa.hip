@@ -1,0 +1,424 @@
+// Fused scaled-dot-product attention (flash style) for the DENSE attention variants of the path:
+// vit.MultiHeadAttention (models/vit.py:95-100), CrossAttention / MultiHeadCrossAttention
+// (models/attention.py:63-75, 131-144) and the nn.MultiheadAttention branch of models/vit_mhla.py:57-62.
+//
+//   S = scale * Q K^T  ->  mask  ->  softmax  ->  dropout  ->  O = P V
+//
+// No [B*H, Lq, Lk] tensor ever reaches HBM: tiles of the streamed operands sit in LDS, both contractions run on
+// MFMA (bf16: v_mfma_f32_16x16x32_bf16; fp32 parity mode: the exact-fp32 v_mfma_f32_16x16x4_f32), the softmax
+// runs in registers with wave shuffles (online, one (max, sum) pair per row), and the forward only stores O and
+// the row log-sum-exp.  The backward recomputes the probabilities from Q, K and that log-sum-exp (two kernels,
+// no atomics, deterministic): dQ per query tile, (dK, dV) per key tile, delta = rowsum(dO * O).
+//
+// One device function serves the three kernels.  An "owner" tile (64 rows, 16 per wave; the rows whose output is
+// accumulated) meets "streamed" rows in blocks of 32 staged in LDS:
+//   MODE 0 forward : owner = queries, streamed = K (A) and V (B):   O^T  += V^T . Pd
+//   MODE 1 dQ      : owner = queries, streamed = K (A) and V (B):   dQ^T += K^T . dS
+//   MODE 2 dK, dV  : owner = keys,    streamed = Q (A) and dO (B):  dK^T += Q^T . dS,  dV^T += dO^T . Pd
+// T1 = A_streamed . A_owner^T (scores) and T2 = B_streamed . B_owner^T (dPd) come out of the MFMA with a lane
+// holding, for ITS owner row (lane & 15), the streamed rows 4g .. 4g+3 (g = lane >> 4) of both 16-row sub-tiles:
+// exactly the k-slice the second MFMA wants as its B operand, so P / dS never leave registers (the transposed A
+// operand is read with ds_read_b64_tr_b16 in the same permuted row order).
+// Output columns are processed in chunks of 16 * NDT <= 128 (blockIdx.z), so any head dim that is a multiple of
+// 16 works (single-head CrossAttention: hd = embed_dim).
+#include "common.h"
+
+namespace {
+
+struct View {
+  long ld, sb, sh;      // element (b, h, l, d) at base + b*sb + h*sh + l*ld + d
+};
+
+struct SdpaArgs {
+  const void* q;
+  const void* k;
+  const void* v;
+  const void* dout;
+  void* out0;           // MODE 0: o    MODE 1: dq    MODE 2: dk
+  void* out1;           //                            MODE 2: dv
+  float* lse;           // [B*H, Lq]  (written by MODE 0, read by 1 / 2)
+  const float* delta;   // [B*H, Lq]  rowsum(dO * O)
+  const uint8_t* mask;
+  long m_sb, m_sq;
+  View vq, vk, vv, vdo, vo0, vo1;
+  int B, H, Lq, Lk, hd, rows_per_block;
+  float scale;
+  uint32_t thresh;
+  float keep_scale;
+  uint64_t seed;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int KC = 32;                       // contraction length of one MFMA
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  // k-slice g of chunk c of a row (elements 32c + 8g .. +7); elements >= hd read as zero
+  static __device__ __forceinline__ frag slice_global(const bf16_t* row, int c, int g, int hd) {
+    const int e0 = 32 * c + 8 * g;
+    if (e0 + 8 <= hd) return *reinterpret_cast<const frag*>(row + e0);
+    frag z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
+    return z;
+  }
+  static __device__ __forceinline__ frag slice_lds(const char* row, int c, int g) {
+    return *reinterpret_cast<const frag*>(row + (32 * c + 8 * g) * 2);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KC = 4;
+  typedef float frag;
+  static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ frag slice_global(const float* row, int c, int g, int hd) {
+    const int e = 4 * c + g;
+    return e < hd ? row[e] : 0.f;
+  }
+  static __device__ __forceinline__ frag slice_lds(const char* row, int c, int g) {
+    return *reinterpret_cast<const float*>(row + (4 * c + g) * 4);
+  }
+};
+
+typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr_t;
+
+// acc[dt] (+)= X^T[d0 + 16 dt ..][rows of the block] . w   with w = the lane's 8 values (sub-tile st = e >> 2,
+// row 4g + (e & 3)) of its owner column.  tile = LDS image of the 32 streamed rows (row stride rs bytes).
+template <typename T, int NDT>
+__device__ __forceinline__ void acc_transposed(f32x4 (&acc)[NDT], const char* tile, int rs, int d0, int lane,
+                                               const float (&w)[8], int ne) {
+  const int g = lane >> 4, n = lane & 15;
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 wf;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wf[e] = (bf16_t)w[e];
+    const int q4 = n >> 2, p4 = n & 3;
+    const char* r0 = tile + (4 * g + q4) * rs + (d0 + 4 * p4) * 2;
+    const char* r1 = tile + (16 + 4 * g + q4) * rs + (d0 + 4 * p4) * 2;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(r0 + 32 * dt));
+      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(r1 + 32 * dt));
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      s16x8 xx;
+      xx[0] = lo4[0]; xx[1] = lo4[1]; xx[2] = lo4[2]; xx[3] = lo4[3];
+      xx[4] = hi4[0]; xx[5] = hi4[1]; xx[6] = hi4[2]; xx[7] = hi4[3];
+      acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xx), wf, acc[dt], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e >= ne) break;                              // 16-row blocks (fp32, very wide heads): sub-tile 0 only
+      const char* row = tile + (16 * (e >> 2) + 4 * g + (e & 3)) * rs + (d0 + n) * 4;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+        acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(*reinterpret_cast<const float*>(row + 64 * dt), w[e], acc[dt], 0, 0, 0);
+    }
+  }
+}
+
+// rows [s0, s0 + 32) x hd of a streamed matrix -> LDS (zero beyond Ls rows and in the padded columns)
+template <typename T>
+__device__ __forceinline__ void stage_tile(char* tile, int rs, const T* base, long ld, int s0, int Ls, int hd,
+                                           int hd_pad, int tid, int nrows) {
+  constexpr int EPC = 16 / (int)sizeof(T);            // elements per 16-byte chunk
+  const int cpr = hd_pad / EPC;
+  for (int c = tid; c < nrows * cpr; c += 256) {
+    const int r = c / cpr, ch = c - r * cpr;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (s0 + r < Ls && (ch + 1) * EPC <= hd) v = *reinterpret_cast<const uint4*>(base + (long)(s0 + r) * ld + ch * EPC);
+    *reinterpret_cast<uint4*>(tile + r * rs + ch * 16) = v;
+  }
+}
+
+template <typename T, int NDT, int MODE>
+__global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef Mma<T> M;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int z = blockIdx.y, b = z / a.H, h = z % a.H;
+  const int d0 = blockIdx.z * (16 * NDT);
+  const int Lo = MODE == 2 ? a.Lk : a.Lq;              // owner rows
+  const int Ls = MODE == 2 ? a.Lq : a.Lk;              // streamed rows
+  const int hd = a.hd;
+  const int hd_pad = (hd + M::KC - 1) / M::KC * M::KC;
+  const int rs = hd_pad * (int)sizeof(T) + 16;
+  const int SB = a.rows_per_block;                     // streamed rows per block: 32, or 16 (fp32, very wide heads)
+  const int ne = SB == 32 ? 8 : 4;
+  char* tileA = smem;
+  char* tileB = smem + SB * rs;
+
+  const T* Q = reinterpret_cast<const T*>(a.q) + b * a.vq.sb + h * a.vq.sh;
+  const T* Kp = reinterpret_cast<const T*>(a.k) + b * a.vk.sb + h * a.vk.sh;
+  const T* V = reinterpret_cast<const T*>(a.v) + b * a.vv.sb + h * a.vv.sh;
+  const T* dO = MODE ? reinterpret_cast<const T*>(a.dout) + b * a.vdo.sb + h * a.vdo.sh : nullptr;
+  const T* ownA = MODE == 2 ? Kp : Q;   const long ownA_ld = MODE == 2 ? a.vk.ld : a.vq.ld;
+  const T* ownB = MODE == 2 ? V : dO;   const long ownB_ld = MODE == 2 ? a.vv.ld : a.vdo.ld;
+  const T* strA = MODE == 2 ? Q : Kp;   const long strA_ld = MODE == 2 ? a.vq.ld : a.vk.ld;
+  const T* strB = MODE == 2 ? dO : V;   const long strB_ld = MODE == 2 ? a.vdo.ld : a.vv.ld;
+
+  const int on = blockIdx.x * 64 + wave * 16 + n;      // this lane's owner row
+  const int onc = min(on, Lo - 1);
+  const T* oa_row = ownA + (long)onc * ownA_ld;
+  const T* ob_row = MODE ? ownB + (long)onc * ownB_ld : nullptr;
+  const long zq = (long)z * a.Lq;
+
+  f32x4 acc0[NDT], acc1[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) { acc0[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  float m_run = -INFINITY, l_run = 0.f;                // MODE 0: online softmax state of the owner (query) row
+  float lse_o = 0.f, delta_o = 0.f;                    // MODE 1: the owner row's statistics
+  if (MODE == 1) { lse_o = a.lse[zq + onc]; delta_o = a.delta[zq + onc]; }
+  const uint8_t* mrow_b = a.mask ? a.mask + (long)b * a.m_sb : nullptr;
+  const int nchunk = hd_pad / M::KC;
+
+  for (int s0 = 0; s0 < Ls; s0 += SB) {
+    __syncthreads();                                   // previous block's LDS reads are complete
+    stage_tile<T>(tileA, rs, strA, strA_ld, s0, Ls, hd, hd_pad, tid, SB);
+    stage_tile<T>(tileB, rs, strB, strB_ld, s0, Ls, hd, hd_pad, tid, SB);
+    __syncthreads();
+
+    f32x4 t1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 t2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const char* ra0 = tileA + n * rs;
+    const char* ra1 = tileA + (16 + n) * rs;
+    const char* rb0 = tileB + n * rs;
+    const char* rb1 = tileB + (16 + n) * rs;
+    for (int c = 0; c < nchunk; ++c) {
+      const typename M::frag fo = M::slice_global(oa_row, c, g, hd);
+      t1[0] = M::mma(M::slice_lds(ra0, c, g), fo, t1[0]);
+      if (SB == 32) t1[1] = M::mma(M::slice_lds(ra1, c, g), fo, t1[1]);
+      if (MODE) {
+        const typename M::frag fb = M::slice_global(ob_row, c, g, hd);
+        t2[0] = M::mma(M::slice_lds(rb0, c, g), fb, t2[0]);
+        if (SB == 32) t2[1] = M::mma(M::slice_lds(rb1, c, g), fb, t2[1]);
+      }
+    }
+
+    // ---- scores of (streamed row s, owner row on); i = query, j = key ----
+    float sc[8], keep[8];
+    bool ok[8];
+    float bm = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int s = s0 + 16 * (e >> 2) + 4 * g + (e & 3);
+      const int i = MODE == 2 ? s : on, j = MODE == 2 ? on : s;
+      ok[e] = (s < Ls) && (on < Lo) && (e < ne);
+      if (ok[e] && mrow_b && mrow_b[(long)i * a.m_sq + j] == 0) ok[e] = false;      // masked_fill(-inf)
+      sc[e] = ok[e] ? t1[e >> 2][e & 3] * a.scale : -INFINITY;
+      keep[e] = 1.f;
+      if (a.thresh && ok[e]) keep[e] = favit_keep(a.seed, (uint64_t)((zq + i) * (long)a.Lk + j), a.thresh) ? a.keep_scale : 0.f;
+      bm = fmaxf(bm, sc[e]);
+    }
+    float wA[8], wB[8];                                // B operands of the transposed products: dS and Pd
+    if (MODE == 0) {
+      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      const float m_new = fmaxf(m_run, bm);
+      const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;       // a fully masked prefix: no NaN in flight
+      const float alpha = __expf(m_run - m_safe);
+      float ls = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float p = __expf(sc[e] - m_safe);
+        ls += p;
+        wB[e] = p * keep[e];
+      }
+      l_run = l_run * alpha + ls;                      // per-lane partial sum (reduced over g at the end)
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        acc1[dt][0] *= alpha; acc1[dt][1] *= alpha; acc1[dt][2] *= alpha; acc1[dt][3] *= alpha;
+      }
+      acc_transposed<T, NDT>(acc1, tileB, rs, d0, lane, wB, ne);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float lse_i = lse_o, dl_i = delta_o;
+        if (MODE == 2) {
+          const int s = min(s0 + 16 * (e >> 2) + 4 * g + (e & 3), Ls - 1);
+          lse_i = a.lse[zq + s];
+          dl_i = a.delta[zq + s];
+        }
+        const float p = ok[e] ? __expf(sc[e] - lse_i) : 0.f;
+        const float dp = t2[e >> 2][e & 3] * keep[e];
+        wA[e] = p * (dp - dl_i) * a.scale;             // dS (times the scale of the scores)
+        wB[e] = p * keep[e];                           // dropped probabilities
+      }
+      acc_transposed<T, NDT>(acc0, tileA, rs, d0, lane, wA, ne);
+      if (MODE == 2) acc_transposed<T, NDT>(acc1, tileB, rs, d0, lane, wB, ne);
+    }
+  }
+
+  // ---- store: the lane holds, for owner row `on`, columns d0 + 16 dt + 4g .. + 3 ----
+  if (MODE == 0) {
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_run;                    // a fully masked row: 0 * inf = NaN, as torch's softmax
+    if (on < Lo) {
+      T* orow = reinterpret_cast<T*>(a.out0) + b * a.vo0.sb + h * a.vo0.sh + (long)on * a.vo0.ld;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int d = d0 + 16 * dt + 4 * g;
+        if (d < hd) {
+          if constexpr (sizeof(T) == 2) {
+            bf16x4 ob = {(bf16_t)(acc1[dt][0] * inv), (bf16_t)(acc1[dt][1] * inv), (bf16_t)(acc1[dt][2] * inv), (bf16_t)(acc1[dt][3] * inv)};
+            *reinterpret_cast<bf16x4*>(orow + d) = ob;
+          } else {
+            *reinterpret_cast<float4*>(orow + d) = make_float4(acc1[dt][0] * inv, acc1[dt][1] * inv, acc1[dt][2] * inv, acc1[dt][3] * inv);
+          }
+        }
+      }
+      if (g == 0 && blockIdx.z == 0) a.lse[zq + on] = m_run + __logf(l_run);
+    }
+  } else if (on < Lo) {
+    auto store = [&](void* base, const View& vw, const f32x4 (&acc)[NDT]) {
+      T* orow = reinterpret_cast<T*>(base) + b * vw.sb + h * vw.sh + (long)on * vw.ld;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int d = d0 + 16 * dt + 4 * g;
+        if (d < hd) {
+          if constexpr (sizeof(T) == 2) {
+            bf16x4 ob = {(bf16_t)acc[dt][0], (bf16_t)acc[dt][1], (bf16_t)acc[dt][2], (bf16_t)acc[dt][3]};
+            *reinterpret_cast<bf16x4*>(orow + d) = ob;
+          } else {
+            *reinterpret_cast<float4*>(orow + d) = make_float4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]);
+          }
+        }
+      }
+    };
+    store(a.out0, a.vo0, acc0);
+    if (MODE == 2) store(a.out1, a.vo1, acc1);
+  }
+}
+
+// delta[z, i] = sum_d dO[i, d] * O[i, d]   (one wave per row)
+template <typename T>
+__global__ __launch_bounds__(256) void sdpa_delta_kernel(const T* __restrict__ o, View vo, const T* __restrict__ dout, View vdo,
+                                                         float* __restrict__ delta, int H, int Lq, int hd, long rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const long z = row / Lq;
+  const int i = (int)(row - z * Lq);
+  const int b = (int)(z / H), h = (int)(z % H);
+  const T* orow = o + b * vo.sb + h * vo.sh + (long)i * vo.ld;
+  const T* grow = dout + b * vdo.sb + h * vdo.sh + (long)i * vdo.ld;
+  float s = 0.f;
+  for (int d = lane; d < hd; d += 64) s = fmaf(to_f32(orow[d]), to_f32(grow[d]), s);
+  s = wave_sum(s);
+  if (lane == 0) delta[row] = s;
+}
+
+template <typename T, int MODE>
+int launch_mode(const SdpaArgs& a_in, hipStream_t st) {
+  SdpaArgs a = a_in;
+  const int Lo = MODE == 2 ? a.Lk : a.Lq;
+  const int kc = Mma<T>::KC;
+  const int hd_pad = (a.hd + kc - 1) / kc * kc;
+  const int rs = hd_pad * (int)sizeof(T) + 16;
+  int lds = 2 * 32 * rs + 1024;            // + slack: unused output columns may read past the last row
+  a.rows_per_block = 32;
+  if (lds > 160 * 1024 && sizeof(T) == 4) {            // fp32 with a very wide head: 16 streamed rows per block
+    a.rows_per_block = 16;
+    lds = 2 * 16 * rs + 1024;
+  }
+  if (lds > 160 * 1024) return FAVIT_ERR_UNSUPPORTED;
+  // output columns per workgroup: the largest of 16 / 32 / 64 / 128 that does not exceed the head dim
+  const int ndt = a.hd >= 128 ? 8 : a.hd >= 64 ? 4 : a.hd >= 32 ? 2 : 1;
+  const dim3 grid((unsigned)((Lo + 63) / 64), (unsigned)(a.B * a.H), (unsigned)((a.hd + 16 * ndt - 1) / (16 * ndt)));
+#define FAVIT_SDPA_LAUNCH(NDT)                                                                            \
+  do {                                                                                                    \
+    if (lds > 65536) favit_ensure_dyn_lds(reinterpret_cast<const void*>(sdpa_kernel<T, NDT, MODE>), lds); \
+    hipLaunchKernelGGL((sdpa_kernel<T, NDT, MODE>), grid, dim3(256), lds, st, a);                         \
+  } while (0)
+  switch (ndt) {
+    case 8: FAVIT_SDPA_LAUNCH(8); break;
+    case 4: FAVIT_SDPA_LAUNCH(4); break;
+    case 2: FAVIT_SDPA_LAUNCH(2); break;
+    default: FAVIT_SDPA_LAUNCH(1); break;
+  }
+#undef FAVIT_SDPA_LAUNCH
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int check(const favit_sdpa_t* s, bool bwd) {
+  if (!s || !s->q || !s->k || !s->v || !s->lse) return FAVIT_ERR_INVALID;
+  if (s->B <= 0 || s->H <= 0 || s->Lq <= 0 || s->Lk <= 0 || s->hd <= 0) return FAVIT_ERR_INVALID;
+  if (s->dtype != FAVIT_F32 && s->dtype != FAVIT_BF16) return FAVIT_ERR_INVALID;
+  if (s->dropout_p < 0.f || s->dropout_p >= 1.f) return FAVIT_ERR_INVALID;
+  if (s->hd % 16) return FAVIT_ERR_UNSUPPORTED;
+  const int vec = s->dtype == FAVIT_BF16 ? 8 : 4;       // 16-byte row chunks: strides in elements
+  const int64_t* str[] = {s->q_str, s->k_str, s->v_str, s->o_str};
+  for (const int64_t* p : str)
+    if (p[0] % vec || p[1] % vec || p[2] % vec) return FAVIT_ERR_ALIGN;
+  if (!al16(s->q) || !al16(s->k) || !al16(s->v)) return FAVIT_ERR_ALIGN;
+  if (!bwd) {
+    if (!s->o || !al16(s->o)) return FAVIT_ERR_INVALID;
+  } else {
+    if (!s->o || !s->dout || !s->dq || !s->dk || !s->dv || !s->delta) return FAVIT_ERR_INVALID;
+    const int64_t* str2[] = {s->do_str, s->dq_str, s->dk_str, s->dv_str};
+    for (const int64_t* p : str2)
+      if (p[0] % vec || p[1] % vec || p[2] % vec) return FAVIT_ERR_ALIGN;
+    if (!al16(s->dout) || !al16(s->dq) || !al16(s->dk) || !al16(s->dv)) return FAVIT_ERR_ALIGN;
+  }
+  return FAVIT_OK;
+}
+
+inline View view(const int64_t* p) { return View{(long)p[0], (long)p[1], (long)p[2]}; }
+
+SdpaArgs base_args(const favit_sdpa_t* s) {
+  SdpaArgs a;
+  a.q = s->q; a.k = s->k; a.v = s->v; a.dout = s->dout;
+  a.out0 = nullptr; a.out1 = nullptr;
+  a.lse = s->lse; a.delta = s->delta;
+  a.mask = s->mask; a.m_sb = (long)s->m_sb; a.m_sq = (long)s->m_sq;
+  a.vq = view(s->q_str); a.vk = view(s->k_str); a.vv = view(s->v_str); a.vdo = view(s->do_str);
+  a.vo0 = view(s->o_str); a.vo1 = view(s->o_str);
+  a.B = s->B; a.H = s->H; a.Lq = s->Lq; a.Lk = s->Lk; a.hd = s->hd; a.rows_per_block = 64;
+  a.scale = s->scale;
+  a.thresh = dropout_threshold(s->dropout_p);
+  a.keep_scale = 1.0f / (1.0f - s->dropout_p);
+  a.seed = s->seed;
+  return a;
+}
+
+}  // namespace
+
+extern "C" int favit_sdpa_fwd(const favit_sdpa_t* s, void* stream) {
+  const int rc = check(s, false);
+  if (rc != FAVIT_OK) return rc;
+  SdpaArgs a = base_args(s);
+  a.out0 = s->o;
+  hipStream_t st = as_stream(stream);
+  return s->dtype == FAVIT_BF16 ? launch_mode<bf16_t, 0>(a, st) : launch_mode<float, 0>(a, st);
+}
+
+extern "C" int favit_sdpa_bwd(const favit_sdpa_t* s, void* stream) {
+  int rc = check(s, true);
+  if (rc != FAVIT_OK) return rc;
+  hipStream_t st = as_stream(stream);
+  const long rows = (long)s->B * s->H * s->Lq;
+  const dim3 dg((unsigned)((rows + 3) / 4));
+  if (s->dtype == FAVIT_BF16)
+    hipLaunchKernelGGL((sdpa_delta_kernel<bf16_t>), dg, dim3(256), 0, st, (const bf16_t*)s->o, view(s->o_str), (const bf16_t*)s->dout,
+                       view(s->do_str), s->delta, s->H, s->Lq, s->hd, rows);
+  else
+    hipLaunchKernelGGL((sdpa_delta_kernel<float>), dg, dim3(256), 0, st, (const float*)s->o, view(s->o_str), (const float*)s->dout,
+                       view(s->do_str), s->delta, s->H, s->Lq, s->hd, rows);
+  FAVIT_CHECK_LAUNCH();
+  SdpaArgs a = base_args(s);
+  a.out0 = s->dq; a.vo0 = view(s->dq_str);
+  rc = s->dtype == FAVIT_BF16 ? launch_mode<bf16_t, 1>(a, st) : launch_mode<float, 1>(a, st);
+  if (rc != FAVIT_OK) return rc;
+  a.out0 = s->dk; a.vo0 = view(s->dk_str);
+  a.out1 = s->dv; a.vo1 = view(s->dv_str);
+  return s->dtype == FAVIT_BF16 ? launch_mode<bf16_t, 2>(a, st) : launch_mode<float, 2>(a, st);
+}

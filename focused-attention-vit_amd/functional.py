@@ -413,6 +413,11 @@ class _View:
 
 
 def sdpa_fwd(q: _View, k: _View, v: _View, o: _View, B, H, Lq, Lk, hd, scale, mask, m_sb, m_sq, p, seed):
+    """softmax(scale * q k^T, masked) (dropout) v on the fused kernel (csrc/sdpa.hip): no [B*H, Lq, Lk] tensor
+    in HBM.  Returns what backward needs: (lse,) -- or, for a head dim the fused kernel does not take (not a
+    multiple of 16), the unfused MFMA-GEMM + softmax chain's (P, Pd)."""
+    if hd % 16 == 0:
+        return (K.sdpa_fwd(q, k, v, o, B, H, Lq, Lk, hd, scale, mask, m_sb, m_sq, p, seed),)
     cdt = q.t.dtype
     Z = B * H
     S = torch.empty((Z, Lq, Lk), dtype=torch.float32, device=q.t.device)
@@ -424,8 +429,12 @@ def sdpa_fwd(q: _View, k: _View, v: _View, o: _View, B, H, Lq, Lk, hd, scale, ma
     return P, Pd
 
 
-def sdpa_bwd(q: _View, k: _View, v: _View, do: _View, dq: _View, dk: _View, dv: _View, P, Pd, B, H, Lq, Lk, hd,
-             scale, p, seed):
+def sdpa_bwd(q: _View, k: _View, v: _View, o: _View, do: _View, dq: _View, dk: _View, dv: _View, saved, B, H, Lq, Lk,
+             hd, scale, mask, m_sb, m_sq, p, seed):
+    if len(saved) == 1:
+        K.sdpa_bwd(q, k, v, o, do, dq, dk, dv, saved[0], B, H, Lq, Lk, hd, scale, mask, m_sb, m_sq, p, seed)
+        return
+    P, Pd = saved
     Z = B * H
     sP = (H * Lq * Lk, Lq * Lk)
     dPd = torch.empty((Z, Lq, Lk), dtype=torch.float32, device=q.t.device)
@@ -522,12 +531,12 @@ class DenseChain:
         o = torch.empty((M, D), dtype=xn.dtype, device=xn.device)
         q, k, v = self._views(qkv, B, L, D, hd)
         ov = _View(o, 0, D, L * D, hd)
-        P, Pd = sdpa_fwd(q, k, v, ov, B, H, L, L, hd, hd ** -0.5, mask, L if mask is not None else 0, 0, pa, sa)
+        att = sdpa_fwd(q, k, v, ov, B, H, L, L, hd, hd ** -0.5, mask, L if mask is not None else 0, 0, pa, sa)
         y = lin_fwd(o, wp_c, bp.detach(), M, D, D, torch.float32, residual=residual, drop=(pp, sp))
-        return y, (xn, wqkv_c, qkv, o, wp_c, P, Pd, B, L, pa, sa, pp, sp, prm)
+        return y, (xn, wqkv_c, qkv, o, wp_c, att, mask, B, L, pa, sa, pp, sp, prm)
 
     def bwd(self, saved, dy_lp):
-        xn, wqkv_c, qkv, o, wp_c, P, Pd, B, L, pa, sa, pp, sp, prm = saved
+        xn, wqkv_c, qkv, o, wp_c, att, mask, B, L, pa, sa, pp, sp, prm = saved
         wqkv, bqkv, wp, bp = prm
         M, D = xn.shape
         H, hd = self.H, D // self.H
@@ -537,7 +546,8 @@ class DenseChain:
         dqkv = torch.empty_like(qkv)
         q, k, v = self._views(qkv, B, L, D, hd)
         dq, dk, dv = self._views(dqkv, B, L, D, hd)
-        sdpa_bwd(q, k, v, _View(do, 0, D, L * D, hd), dq, dk, dv, P, Pd, B, H, L, L, hd, hd ** -0.5, pa, sa)
+        sdpa_bwd(q, k, v, _View(o, 0, D, L * D, hd), _View(do, 0, D, L * D, hd), dq, dk, dv, att, B, H, L, L, hd,
+                 hd ** -0.5, mask, L if mask is not None else 0, 0, pa, sa)
         dxn = lin_bwd_x(dqkv, wqkv_c, M, 3 * D, D, xn.dtype)
         dwqkv, dbqkv = lin_bwd_w(dqkv, xn, M, 3 * D, D, wp=wqkv, bp=bqkv)
         return dxn, [dwqkv, dbqkv, dwp, dbp]
@@ -565,14 +575,14 @@ class CrossChain:
         v = lin_fwd(kn, wv_c, bv.detach(), B * Lk, D, D, cdt)
         o = torch.empty((B * Lq, D), dtype=cdt, device=qn.device)
         scale = 1.0 / (hd ** 0.5)
-        P, Pd = sdpa_fwd(_View(q, 0, D, Lq * D, hd), _View(k, 0, D, Lk * D, hd), _View(v, 0, D, Lk * D, hd),
-                         _View(o, 0, D, Lq * D, hd), B, H, Lq, Lk, hd, scale, mask,
-                         Lq * Lk if mask is not None else 0, Lk if mask is not None else 0, pa, sa)
+        att = sdpa_fwd(_View(q, 0, D, Lq * D, hd), _View(k, 0, D, Lk * D, hd), _View(v, 0, D, Lk * D, hd),
+                       _View(o, 0, D, Lq * D, hd), B, H, Lq, Lk, hd, scale, mask,
+                       Lq * Lk if mask is not None else 0, Lk if mask is not None else 0, pa, sa)
         y = lin_fwd(o, wo_c, bo.detach(), B * Lq, D, D, torch.float32, residual=residual)
-        return y, (qn, kn, q, k, v, o, (wq_c, wk_c, wv_c, wo_c), P, Pd, B, Lq, Lk, pa, sa, scale, prm)
+        return y, (qn, kn, q, k, v, o, (wq_c, wk_c, wv_c, wo_c), att, mask, B, Lq, Lk, pa, sa, scale, prm)
 
     def bwd(self, saved, dy_lp):
-        qn, kn, q, k, v, o, (wq_c, wk_c, wv_c, wo_c), P, Pd, B, Lq, Lk, pa, sa, scale, prm = saved
+        qn, kn, q, k, v, o, (wq_c, wk_c, wv_c, wo_c), att, mask, B, Lq, Lk, pa, sa, scale, prm = saved
         wq, bq, wk, bk, wv, bv, wo, bo = prm
         D = qn.shape[1]
         H, hd = self.H, D // self.H
@@ -582,8 +592,9 @@ class CrossChain:
         dwo, dbo = lin_bwd_w(dy_lp, o, Mq, D, D, wp=wo, bp=bo)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         sdpa_bwd(_View(q, 0, D, Lq * D, hd), _View(k, 0, D, Lk * D, hd), _View(v, 0, D, Lk * D, hd),
-                 _View(do, 0, D, Lq * D, hd), _View(dq, 0, D, Lq * D, hd), _View(dk, 0, D, Lk * D, hd),
-                 _View(dv, 0, D, Lk * D, hd), P, Pd, B, H, Lq, Lk, hd, scale, pa, sa)
+                 _View(o, 0, D, Lq * D, hd), _View(do, 0, D, Lq * D, hd), _View(dq, 0, D, Lq * D, hd),
+                 _View(dk, 0, D, Lk * D, hd), _View(dv, 0, D, Lk * D, hd), att, B, H, Lq, Lk, hd, scale, mask,
+                 Lq * Lk if mask is not None else 0, Lk if mask is not None else 0, pa, sa)
         dqn = lin_bwd_x(dq, wq_c, Mq, D, D, cdt)
         dwq, dbq = lin_bwd_w(dq, qn, Mq, D, D, wp=wq, bp=bq)
         dkn = torch.empty((Mk, D), dtype=torch.float32, device=qn.device)

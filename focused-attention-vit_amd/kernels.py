@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _abi
-from ._abi import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, GemmDesc
+from ._abi import ACT_DGELU, ACT_GELU, ACT_NONE, BF16, F32, GemmDesc, SdpaDesc
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -295,6 +295,43 @@ def mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask=None, p=0.0, seed=0):
     _abi.check(_abi.lib().favit_mhla_attn_bwd(_p(qkv), _p(dout), _p(dqkv), _p(mask), B, L, H, hd, W, dt(qkv), p, seed,
                                               _st()), "favit_mhla_attn_bwd")
     return dqkv
+
+
+def _sdpa_desc(q, k, v, o, lse, B, H, Lq, Lk, hd, scale, mask, m_sb, m_sq, p, seed):
+    """q, k, v, o: (tensor, element offset, row stride, batch stride, head stride) views (functional._View)."""
+    d = SdpaDesc()
+    es = q.t.element_size()
+    for name, vw in (("q", q), ("k", k), ("v", v), ("o", o)):
+        setattr(d, name, vw.t.data_ptr() + vw.off * es)
+        getattr(d, name + "_str")[:] = [vw.ld, vw.sb, vw.sh]
+    d.lse = lse.data_ptr()
+    d.mask = mask.data_ptr() if mask is not None else None
+    d.m_sb, d.m_sq = m_sb, m_sq
+    d.B, d.H, d.Lq, d.Lk, d.hd, d.dtype = B, H, Lq, Lk, hd, dt(q.t)
+    d.scale, d.dropout_p, d.seed = scale, p, seed
+    return d
+
+
+def sdpa_fwd(q, k, v, o, B, H, Lq, Lk, hd, scale, mask=None, m_sb=0, m_sq=0, p=0.0, seed=0):
+    """Fused attention forward: writes o (view) and returns lse [B*H, Lq] fp32 (saved for backward)."""
+    require_gpu(q.t, k.t, v.t, o.t, mask)
+    lse = torch.empty((B * H, Lq), dtype=torch.float32, device=q.t.device)
+    d = _sdpa_desc(q, k, v, o, lse, B, H, Lq, Lk, hd, scale, mask, m_sb, m_sq, p, seed)
+    _abi.check(_abi.lib().favit_sdpa_fwd(C.byref(d), _st()), "favit_sdpa_fwd")
+    return lse
+
+
+def sdpa_bwd(q, k, v, o, do, dq, dk, dv, lse, B, H, Lq, Lk, hd, scale, mask=None, m_sb=0, m_sq=0, p=0.0, seed=0):
+    """Fused attention backward: writes dq, dk, dv (views); probabilities are recomputed from lse."""
+    require_gpu(q.t, k.t, v.t, o.t, do.t, dq.t, dk.t, dv.t, lse, mask)
+    delta = torch.empty((B * H, Lq), dtype=torch.float32, device=q.t.device)
+    d = _sdpa_desc(q, k, v, o, lse, B, H, Lq, Lk, hd, scale, mask, m_sb, m_sq, p, seed)
+    es = q.t.element_size()
+    for name, vw in (("dout", do), ("dq", dq), ("dk", dk), ("dv", dv)):
+        setattr(d, name, vw.t.data_ptr() + vw.off * es)
+        getattr(d, ("do" if name == "dout" else name) + "_str")[:] = [vw.ld, vw.sb, vw.sh]
+    d.delta = delta.data_ptr()
+    _abi.check(_abi.lib().favit_sdpa_bwd(C.byref(d), _st()), "favit_sdpa_bwd")
 
 
 def softmax_fwd(S, p_dtype, H, Z, Lq, Lk, mask=None, m_sb=0, m_sq=0, p=0.0, seed=0):

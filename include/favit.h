@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FAVIT_ABI_VERSION 2
+#define FAVIT_ABI_VERSION 3
 
 enum { FAVIT_F32 = 0, FAVIT_BF16 = 1, FAVIT_FP8 = 2 };
 /* OCP 8-bit float formats of gfx950 (NOT the MI300X fnuz encodings) */
@@ -193,6 +193,42 @@ int favit_softmax_fwd(const float* S, void* P, void* Pd, int p_dtype, const uint
                       void* stream);
 int favit_softmax_bwd(const void* P, int p_dtype, const float* dPd, void* dS, int ds_dtype, int64_t Z, int32_t Lq,
                       int32_t Lk, float dropout_p, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused scaled-dot-product attention for the dense variants (replaces, on one kernel family, the reference's
+ *   scores = q @ k^T * scale -> masked_fill(mask == 0, -inf) -> softmax -> dropout -> @ v
+ * of models/vit.py:95-100 (MultiHeadAttention), models/attention.py:63-75 (CrossAttention, one head,
+ * scale 1/sqrt(embed_dim)) and 131-144 (MultiHeadCrossAttention), and of the nn.MultiheadAttention branch
+ * models/vit_mhla.py:57-62).  No [B*H, Lq, Lk] tensor is written to memory.
+ * Element (b, h, l, d) of a matrix lives at ptr + b*str[1] + h*str[2] + l*str[0] + d (strides in elements,
+ * str = {row stride, batch stride, head stride}; multiples of 16 bytes), so q / k / v can be column blocks of
+ * one fused projection output and o / dq / dk / dv are written in place, head-merged.
+ * mask (uint8, 0 = -inf, NULL = none) is addressed mask[b*m_sb + q*m_sq + k]  (key-keep [B,Lk]: m_sq = 0).
+ * fwd writes o and lse [B*H, Lq] (row log-sum-exp of the scaled, masked scores); bwd needs q, k, v, o, dout,
+ * lse and a workspace delta [B*H, Lq], and writes dq, dk, dv (probabilities are recomputed; deterministic).
+ * dropout: inverted, counter-based on (seed, ((b*H + h)*Lq + q)*Lk + k), the same draw in fwd and bwd.
+ * dtype FAVIT_BF16 (bf16 MFMA, fp32 accumulate / softmax) or FAVIT_F32 (exact-fp32 MFMA); hd % 16 == 0.
+ * ---------------------------------------------------------------------------------- */
+typedef struct favit_sdpa {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;               /* fwd: output; bwd: input */
+  float* lse;            /* fwd: output; bwd: input */
+  const void* dout;      /* bwd only from here */
+  void* dq;
+  void* dk;
+  void* dv;
+  float* delta;
+  const uint8_t* mask;
+  int64_t m_sb, m_sq;
+  int64_t q_str[3], k_str[3], v_str[3], o_str[3], do_str[3], dq_str[3], dk_str[3], dv_str[3];
+  int32_t B, H, Lq, Lk, hd, dtype;
+  float scale, dropout_p;
+  uint64_t seed;
+} favit_sdpa_t;
+int favit_sdpa_fwd(const favit_sdpa_t* s, void* stream);
+int favit_sdpa_bwd(const favit_sdpa_t* s, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Patch embedding front end.

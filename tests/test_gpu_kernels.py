@@ -291,6 +291,99 @@ def test_softmax_fwd_bwd(K, dtype):
     assert rel_l2(dS.float(), Sr.grad) < (2e-5 if dtype == torch.float32 else 2e-2)
 
 
+def _sdpa_views(favit, B, H, L, hd, t, col0, ld):
+    V = favit.functional._View
+    return V(t, col0, ld, L * ld, hd)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Lq,Lk,hd,mask_kind", [(2, 3, 65, 65, 64, None), (2, 4, 17, 17, 16, None), (3, 2, 5, 40, 32, "full"),
+                                                  (2, 1, 33, 20, 64, "keys"), (1, 2, 197, 197, 64, None), (2, 1, 9, 9, 768, "full"),
+                                                  (1, 3, 70, 100, 48, "keys"), (2, 2, 1, 1, 16, None), (1, 1, 130, 64, 192, None),
+                                                  (2, 5, 64, 32, 128, "full")])
+def test_sdpa_fused_fwd_bwd(K, favit, dtype, B, H, Lq, Lk, hd, mask_kind):
+    """The fused attention kernels (forward, dQ, dK/dV) against softmax(q k^T * scale, masked) v in fp32 torch:
+    separate and interleaved operand layouts, both mask forms, head dims that need padding (16, 48) and
+    column chunking (192, 768), Lq != Lk, single-row problems."""
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + Lq * 10 + hd)
+    D = H * hd
+    V = favit.functional._View
+    self_attn = Lq == Lk
+    if self_attn:        # q, k, v interleaved in one [B*L, 3D] buffer, as the fused qkv projection writes them
+        qkv = _rand((B * Lq, 3 * D), dtype, g)
+        q, k, v = (V(qkv, s * D, 3 * D, Lq * 3 * D, hd) for s in range(3))
+        qf, kf, vf = (qkv.float().reshape(B, Lq, 3, H, hd)[:, :, s].permute(0, 2, 1, 3) for s in range(3))
+    else:
+        qt, kt, vt = _rand((B * Lq, D), dtype, g), _rand((B * Lk, D), dtype, g), _rand((B * Lk, D), dtype, g)
+        q, k, v = V(qt, 0, D, Lq * D, hd), V(kt, 0, D, Lk * D, hd), V(vt, 0, D, Lk * D, hd)
+        qf = qt.float().reshape(B, Lq, H, hd).permute(0, 2, 1, 3)
+        kf, vf = (t.float().reshape(B, Lk, H, hd).permute(0, 2, 1, 3) for t in (kt, vt))
+    mask, m_sb, m_sq, mb = None, 0, 0, None
+    if mask_kind == "full":
+        mb = torch.rand(B, Lq, Lk, generator=g, device=DEV) > 0.4
+        mb[..., 0] = True
+        mask, m_sb, m_sq = mb.to(torch.uint8).contiguous(), Lq * Lk, Lk
+        mb = mb[:, None]
+    elif mask_kind == "keys":
+        mk = torch.rand(B, Lk, generator=g, device=DEV) > 0.3
+        mk[:, 0] = True
+        mask, m_sb, m_sq = mk.to(torch.uint8).contiguous(), Lk, 0
+        mb = mk[:, None, None, :]
+    scale = 1.0 / math.sqrt(hd)
+    ot = torch.empty((B * Lq, D), dtype=dtype, device=DEV)
+    o = V(ot, 0, D, Lq * D, hd)
+    lse = K.sdpa_fwd(q, k, v, o, B, H, Lq, Lk, hd, scale, mask, m_sb, m_sq)
+    qr, kr, vr = (t.detach().clone().requires_grad_(True) for t in (qf, kf, vf))
+    sr = (qr @ kr.transpose(-2, -1)) * scale
+    if mb is not None:
+        sr = sr.masked_fill(~mb, float("-inf"))
+    oref = torch.softmax(sr, -1) @ vr                                    # [B, H, Lq, hd]
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(ot.float().reshape(B, Lq, H, hd).permute(0, 2, 1, 3), oref) < tol
+    assert rel_l2(lse.reshape(B, H, Lq), torch.logsumexp(sr, -1)) < 2e-5 + (0 if dtype == torch.float32 else 3e-3)
+    dot = _rand((B * Lq, D), dtype, g)
+    dqt = torch.empty((B * Lq, D), dtype=dtype, device=DEV)
+    dkt, dvt = (torch.empty((B * Lk, D), dtype=dtype, device=DEV) for _ in range(2))
+    K.sdpa_bwd(q, k, v, o, V(dot, 0, D, Lq * D, hd), V(dqt, 0, D, Lq * D, hd), V(dkt, 0, D, Lk * D, hd),
+               V(dvt, 0, D, Lk * D, hd), lse, B, H, Lq, Lk, hd, scale, mask, m_sb, m_sq)
+    oref.backward(dot.float().reshape(B, Lq, H, hd).permute(0, 2, 1, 3))
+    gtol = 5e-5 if dtype == torch.float32 else 2e-2
+    for got, ref, L in ((dqt, qr.grad, Lq), (dkt, kr.grad, Lk), (dvt, vr.grad, Lk)):
+        assert rel_l2(got.float().reshape(B, L, H, hd).permute(0, 2, 1, 3), ref) < gtol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sdpa_fused_dropout_consistency(K, favit, dtype):
+    """Train-mode attention dropout of the dense variants: forward and both backward kernels draw the same
+    mask (the output is linear in V: <dO, O(V)> == <dV, V>), the keep rate is 1 - p, another seed differs."""
+    B, H, L, hd, p = 2, 2, 70, 32, 0.25
+    D = H * hd
+    V = favit.functional._View
+    g = torch.Generator(device=DEV).manual_seed(77)
+    qkv = _rand((B * L, 3 * D), dtype, g)
+    q, k, v = (V(qkv, s * D, 3 * D, L * 3 * D, hd) for s in range(3))
+    ot = torch.empty((B * L, D), dtype=dtype, device=DEV)
+    o = V(ot, 0, D, L * D, hd)
+    lse = K.sdpa_fwd(q, k, v, o, B, H, L, L, hd, hd ** -0.5, p=p, seed=5)
+    dot = _rand((B * L, D), dtype, g)
+    dqkv = torch.empty_like(qkv)
+    dq, dk, dv = (V(dqkv, s * D, 3 * D, L * 3 * D, hd) for s in range(3))
+    K.sdpa_bwd(q, k, v, o, V(dot, 0, D, L * D, hd), dq, dk, dv, lse, B, H, L, L, hd, hd ** -0.5, p=p, seed=5)
+    lhs = (dot.float() * ot.float()).sum().item()
+    rhs = (dqkv[:, 2 * D:].float() * qkv[:, 2 * D:].float()).sum().item()
+    scale = (dot.float() * ot.float()).pow(2).sum().sqrt().item()
+    assert abs(lhs - rhs) < (1e-3 if dtype == torch.float32 else 3e-2) * scale
+    ot2 = torch.empty_like(ot)
+    K.sdpa_fwd(q, k, v, V(ot2, 0, D, L * D, hd), B, H, L, L, hd, hd ** -0.5, p=p, seed=6)
+    assert not torch.allclose(ot.float(), ot2.float())
+    # with V = ones the output row is sum_j Pd_ij = (kept mass) / (1 - p): its mean over rows is ~1
+    ones = qkv.clone()
+    ones[:, 2 * D:] = 1.0
+    K.sdpa_fwd(*(V(ones, s * D, 3 * D, L * 3 * D, hd) for s in range(3)), V(ot2, 0, D, L * D, hd), B, H, L, L, hd,
+               hd ** -0.5, p=p, seed=9)
+    assert abs(ot2.float().mean().item() - 1.0) < 0.03
+
+
 def test_cross_entropy_and_adamw(K):
     B, Cn = 37, 1000
     logits = torch.randn(B, Cn, device=DEV) * 3
