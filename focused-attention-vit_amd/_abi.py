@@ -80,6 +80,9 @@ _SIGS = {
     "favit_sppp_pool_bwd": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], C.c_int),
     "favit_sppp_centroids": ([vp, vp, i32, i32, i32, vp], C.c_int),
     "favit_sppp_posenc_fwd": ([vp, vp, vp, i32, i32, i32, i32, vp], C.c_int),
+    "favit_slic_features": ([vp, vp, i32, i32, i32, f32, vp], C.c_int),
+    "favit_slic_cluster": ([vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, vp], C.c_int),
+    "favit_slic_connect": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, vp], C.c_int),
     "favit_cross_entropy": ([vp, vp, vp, vp, i32, i32, f32, vp], C.c_int),
     "favit_adamw": ([vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp], C.c_int),
 }

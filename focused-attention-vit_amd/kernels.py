@@ -443,6 +443,54 @@ def sppp_posenc_fwd(x, cent):
     return y
 
 
+def slic_grid(H, W, n_segments):
+    """Seed grid of skimage.segmentation.slic for a 2-D image (skimage.util.regular_grid on (1, H, W)): returns
+    (ys, xs, step) -- seeds at start + i*stride per axis, start = floor(s/2), stride = round(s), s = sqrt(H*W/n)."""
+    import math
+    if H * W <= n_segments:
+        return list(range(H)), list(range(W)), 1
+    s = math.sqrt(H * W / float(n_segments))
+    sy = sx = s
+    if min(H, W) < s:                      # regular_grid: a dimension shorter than the step gets step = its length
+        if H <= W:
+            sy, sx = float(H), (W / float(n_segments))
+        else:
+            sx, sy = float(W), (H / float(n_segments))
+    ys = list(range(int(sy // 2), H, max(1, int(round(sy)))))
+    xs = list(range(int(sx // 2), W, max(1, int(round(sx)))))
+    return ys, xs, max(max(1, int(round(sy))), max(1, int(round(sx))))
+
+
+def slic(images, n_segments=16, compactness=0.1, sigma=1.0, max_num_iter=10, min_size_factor=0.5, stages=False):
+    """SLIC label maps [B,H,W] int64 of fp32 images [B,3,H,W] on the device (csrc/slic.hip; parity with
+    scikit-image unpinned, see include/favit.h).  stages=True also returns (feat, cluster_labels, n_regions)."""
+    require_gpu(images)
+    if images.dim() != 4 or images.shape[1] != 3 or images.dtype != torch.float32:
+        raise TypeError("slic expects fp32 images [B, 3, H, W]")
+    images = images.contiguous()
+    B, _, H, W = images.shape
+    ys, xs, step = slic_grid(H, W, n_segments)
+    if len(ys) * len(xs) > 64:
+        raise ValueError("slic: at most 64 seed centres are supported")
+    dev = images.device
+    init = torch.tensor([[y, x] for y in ys for x in xs], dtype=torch.int32, device=dev)
+    Kc = init.shape[0]
+    coef = int(round((step / float(compactness)) ** 2))
+    min_size = int(min_size_factor * (H * W / float(Kc)))
+    feat = torch.empty((B, H * W, 4), dtype=torch.int16, device=dev)
+    lab = torch.empty((B, H * W), dtype=torch.uint8, device=dev)
+    ws = torch.empty((2, B, H * W), dtype=torch.int32, device=dev)
+    out = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    nreg = torch.empty(B, dtype=torch.int32, device=dev)
+    L = _abi.lib()
+    _abi.check(L.favit_slic_features(_p(images), _p(feat), B, H, W, float(sigma), _st()), "favit_slic_features")
+    _abi.check(L.favit_slic_cluster(_p(feat), _p(lab), _p(init), Kc, B, H, W, step, coef, max_num_iter, _st()),
+               "favit_slic_cluster")
+    _abi.check(L.favit_slic_connect(_p(lab), _p(ws[0]), _p(ws[1]), _p(out), _p(nreg), B, H, W, min_size, _st()),
+               "favit_slic_connect")
+    return (out, feat, lab.view(B, H, W), nreg) if stages else out
+
+
 def cross_entropy(logits, labels, grad_scale=None):
     """Returns (loss_rows[B], dlogits or None)."""
     require_gpu(logits, labels)

@@ -32,17 +32,23 @@ class SuperpixelSegmentation:
         self._maps = maps
 
     def segment(self, image: torch.Tensor) -> torch.Tensor:
+        """Label maps [B,H,W] (or [H,W]) int64.  Installed maps win; images on the GPU run the device SLIC
+        (csrc/slic.hip: no D2H -> skimage -> H2D hop per image; parity with scikit-image is unpinned, the
+        algorithm and its checked properties are in DESIGN.md); CPU images go to scikit-image like the reference."""
         if self._maps is not None:
             maps = self._maps
             return maps if image.dim() == 4 else maps[0]
+        batch_mode = image.dim() == 4
+        imgs = image if batch_mode else image[None]
+        if imgs.is_cuda:
+            seg = K.slic(imgs.float(), n_segments=self.num_segments, compactness=self.compactness, sigma=self.sigma)
+            return seg if batch_mode else seg[0]
         try:
             from skimage.segmentation import slic
         except ImportError as e:
             raise ImportError(
-                "SuperpixelSegmentation.segment needs scikit-image's SLIC (third-party CPU algorithm, not part "
-                "of the accelerated path). Install scikit-image or provide label maps via set_label_maps().") from e
-        batch_mode = image.dim() == 4
-        imgs = image if batch_mode else image[None]
+                "SuperpixelSegmentation.segment on CPU tensors needs scikit-image's SLIC (third-party, not in this "
+                "image); move the images to the GPU (device SLIC) or provide label maps via set_label_maps().") from e
         out = []
         for i in range(imgs.shape[0]):
             img = imgs[i].permute(1, 2, 0).cpu().numpy()

@@ -195,6 +195,25 @@ int favit_softmax_bwd(const void* P, int p_dtype, const float* dPd, void* dS, in
                       int32_t Lk, float dropout_p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * SLIC superpixels on the device: replaces the per-image D2H -> skimage.segmentation.slic -> H2D
+ * hop of SuperpixelSegmentation.segment (reference models/sppp.py:44-74).  scikit-image is an unpinned third-party
+ * dependency absent from the image: parity with skimage is UNPINNED; the algorithm (csrc/slic.hip header) is the
+ * published SLIC as skimage parametrises it, integer-exact after the colour conversion, and is checked against
+ * the CPU restatement oracle/slic_oracle.py.
+ *   features: img fp32 [B,3,H,W] -> feat int16 [B,H*W,4] = round(16 * CIELAB(gaussian_sigma(img))), lane 3 = 0
+ *   cluster : k-means, K <= 64 centres seeded at init_yx [K,2] (int32 y, x), window +-2*step, distance
+ *             256*spatial^2 + coef*dq^2 (int64), `iters` rounds (early exit at a fixed point) -> labels uint8 [B,H*W]
+ *   connect : 4-connected components in raster order, components < min_size merged into a labelled neighbour,
+ *             consecutive labels from 0 -> out int64 [B,H*W]; n_regions int32 [B] (-1: more than 2048 components,
+ *             out = the cluster map); ws_comp / ws_aux: int32 [B,H*W] workspaces.
+ * ---------------------------------------------------------------------------------- */
+int favit_slic_features(const float* img, int16_t* feat, int32_t B, int32_t H, int32_t W, float sigma, void* stream);
+int favit_slic_cluster(const int16_t* feat, uint8_t* labels, const int32_t* init_yx, int32_t K, int32_t B, int32_t H,
+                       int32_t W, int32_t step, int64_t coef, int32_t iters, void* stream);
+int favit_slic_connect(const uint8_t* labels, int32_t* ws_comp, int32_t* ws_aux, int64_t* out, int32_t* n_regions,
+                       int32_t B, int32_t H, int32_t W, int32_t min_size, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention for the dense variants (replaces, on one kernel family, the reference's
  *   scores = q @ k^T * scale -> masked_fill(mask == 0, -inf) -> softmax -> dropout -> @ v
  * of models/vit.py:95-100 (MultiHeadAttention), models/attention.py:63-75 (CrossAttention, one head,
