@@ -80,6 +80,7 @@ _SIGS = {
     "favit_sppp_pool_bwd": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], C.c_int),
     "favit_sppp_centroids": ([vp, vp, i32, i32, i32, vp], C.c_int),
     "favit_sppp_posenc_fwd": ([vp, vp, vp, i32, i32, i32, i32, vp], C.c_int),
+    "favit_image_transform": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp], C.c_int),
     "favit_slic_features": ([vp, vp, i32, i32, i32, f32, vp], C.c_int),
     "favit_slic_cluster": ([vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, vp], C.c_int),
     "favit_slic_connect": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, vp], C.c_int),

@@ -195,6 +195,19 @@ int favit_softmax_bwd(const void* P, int p_dtype, const float* dPd, void* dS, in
                       int32_t Lk, float dropout_p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Device-side input transforms (reference utils/data_utils.py:21-81): crop (+ zero padding) ->
+ * optional flip -> Pillow-exact bilinear resize (8-bit two-pass resampling, 22-bit fixed-point coefficients:
+ * bit-identical to PIL.Image.resize(BILINEAR), which is what torchvision's Resize / RandomResizedCrop run on PIL
+ * images) -> output window -> ToTensor (/255) -> Normalize, for a batch of raw uint8 HWC images on the device.
+ *   src [B,Hs,Ws,C] uint8; params int32 [B,12] (device) = crop top, left, h, w (in the padded source), pad,
+ *   resized h, w, window origin y, x, flip_src, flip_out, 0; tmp uint8 [B,ch_max,S,C] workspace (ch_max >= every
+ *   crop height); out fp32 [B,C,S,S]; out_u8 (optional) the resized bytes [B,S,S,C]; mean / std: HOST arrays [C].
+ * ---------------------------------------------------------------------------------- */
+int favit_image_transform(const uint8_t* src, uint8_t* tmp, float* out, uint8_t* out_u8, const int32_t* params, int32_t B,
+                          int32_t Hs, int32_t Ws, int32_t C, int32_t ch_max, int32_t S, const float* mean,
+                          const float* std, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * SLIC superpixels on the device: replaces the per-image D2H -> skimage.segmentation.slic -> H2D
  * hop of SuperpixelSegmentation.segment (reference models/sppp.py:44-74).  scikit-image is an unpinned third-party
  * dependency absent from the image: parity with skimage is UNPINNED; the algorithm (csrc/slic.hip header) is the

@@ -1,0 +1,133 @@
+"""Device input pipeline (reference utils/data_utils.py:21-81, utils/metrics.py:152-308).
+
+torchvision is not importable here; its Resize / RandomResizedCrop on PIL images are Pillow's
+Image.resize(BILINEAR), and Pillow IS importable, so Pillow is the checker: the device resize must reproduce its
+bytes EXACTLY (8-bit two-pass resampling with fixed-point coefficients), and ToTensor / Normalize follow in fp32.
+Random augmentation parameters have no parity target (torch's RNG stream inside torchvision is not reproduced):
+they are passed explicitly here and only their distributions are checked.
+"""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+DEV = "cuda"
+
+
+def _pil_pipeline(img_u8, top, left, ch, cw, pad, rh, rw, oy, ox, S, flip_src, flip_out, mean, std):
+    """crop (of the zero-padded image) -> flip -> PIL bilinear resize -> window -> flip -> ToTensor -> Normalize"""
+    H, W, C = img_u8.shape
+    padded = np.zeros((H + 2 * pad, W + 2 * pad, C), dtype=np.uint8)
+    padded[pad:pad + H, pad:pad + W] = img_u8
+    crop = padded[top:top + ch, left:left + cw]
+    if flip_src:
+        crop = crop[:, ::-1]
+    res = np.asarray(Image.fromarray(np.ascontiguousarray(crop)).resize((rw, rh), Image.BILINEAR))
+    win = res[oy:oy + S, ox:ox + S]
+    if flip_out:
+        win = win[:, ::-1]
+    t = torch.from_numpy(np.ascontiguousarray(win)).permute(2, 0, 1).float().div(255)
+    m, s = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+    return np.ascontiguousarray(win), (t - m) / s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,S,case", [(32, 32, 224, "cifar_train"), (32, 32, 224, "resize"), (32, 32, 32, "cifar_train"),
+                                        (180, 240, 224, "imagenet_test"), (375, 500, 224, "imagenet_test"),
+                                        (300, 400, 224, "imagenet_train"), (64, 48, 96, "imagenet_train"),
+                                        (500, 333, 64, "imagenet_test")])
+def test_device_transform_is_bit_identical_to_pillow(favit, H, W, S, case):
+    D = favit.data
+    rs = np.random.RandomState(H * 7 + W + S)
+    B = 5
+    imgs = rs.randint(0, 256, size=(B, H, W, 3), dtype=np.uint8)
+    imgs[0, :, :, :] = (np.add.outer(np.arange(H), np.arange(W))[:, :, None] * 3 % 256).astype(np.uint8)   # smooth ramp
+    kind = {"cifar_train": "cifar10_train", "resize": "resize", "imagenet_test": "imagenet_test", "imagenet_train": "imagenet_train"}[case]
+    tf = D.DeviceTransform(kind, S, D.IMAGENET_MEAN, D.IMAGENET_STD, seed=3)
+    prm = tf.params(B, H, W)
+    out, u8 = tf(torch.from_numpy(imgs).to(DEV), params=prm, want_bytes=True)
+    out, u8 = out.cpu(), u8.cpu().numpy()
+    for b in range(B):
+        top, left, ch, cw, pad, rh, rw, oy, ox, fs, fo, _ = [int(v) for v in prm[b]]
+        ref_u8, ref_f = _pil_pipeline(imgs[b], top, left, ch, cw, pad, rh, rw, oy, ox, S, fs, fo, D.IMAGENET_MEAN, D.IMAGENET_STD)
+        np.testing.assert_array_equal(u8[b], ref_u8)                       # byte work: bit-exact
+        assert torch.equal(out[b], ref_f), (out[b] - ref_f).abs().max()    # same fp32 operations as torch
+
+
+def test_transform_parameter_distributions(favit):
+    """CPU: the random parameters follow torchvision's rules (no GPU needed to draw them)."""
+    D = favit.data
+    tf = D.DeviceTransform("cifar10_train", 224, D.CIFAR10_MEAN, D.CIFAR10_STD, seed=1)
+    p = tf.params(4000, 32, 32)
+    assert p[:, 0].min() == 0 and p[:, 0].max() == 8 and p[:, 1].min() == 0 and p[:, 1].max() == 8    # RandomCrop(32, padding=4)
+    assert (p[:, 2] == 32).all() and (p[:, 4] == 4).all() and (p[:, 5] == 224).all()
+    assert abs(p[:, 9].mean() - 0.5) < 0.03 and (p[:, 10] == 0).all()
+    tf = D.DeviceTransform("imagenet_train", 224, D.IMAGENET_MEAN, D.IMAGENET_STD, seed=2)
+    p = tf.params(4000, 375, 500)
+    area = p[:, 2] * p[:, 3] / (375.0 * 500.0)
+    ratio = p[:, 3] / p[:, 2].astype(np.float64)
+    assert area.min() >= 0.07 and area.max() <= 1.0 and 0.74 <= ratio.min() and ratio.max() <= 1.34    # scale (0.08,1), ratio (3/4,4/3)
+    assert (p[:, 0] + p[:, 2] <= 375).all() and (p[:, 1] + p[:, 3] <= 500).all()
+    assert abs(p[:, 10].mean() - 0.5) < 0.03
+    tf = D.DeviceTransform("imagenet_test", 224, D.IMAGENET_MEAN, D.IMAGENET_STD)
+    p = tf.params(1, 375, 500)[0]
+    assert (p[5], p[6]) == (255, 340) and (p[7], p[8]) == (16, 58)           # Resize(255) -> CenterCrop(224)
+    assert set(D.get_transforms("cifar10", 224)) == {"train", "test"}
+
+
+@pytest.mark.gpu
+def test_device_loader_matches_direct_transform_and_overlaps(favit):
+    D = favit.data
+    rs = np.random.RandomState(0)
+    batches = [(rs.randint(0, 256, size=(16, 32, 32, 3), dtype=np.uint8), rs.randint(0, 10, size=16)) for _ in range(5)]
+    tf = D.DeviceTransform("resize", 64, D.CIFAR10_MEAN, D.CIFAR10_STD)
+    loader = D.DeviceLoader(batches, tf)
+    assert len(loader) == 5
+    seen = 0
+    for (x, y), (hi, hl) in zip(loader, batches):
+        assert x.is_cuda and tuple(x.shape) == (16, 3, 64, 64) and y.dtype == torch.int64
+        ref = tf(torch.from_numpy(hi).to(DEV))
+        assert torch.equal(x, ref) and torch.equal(y.cpu(), torch.from_numpy(hl))
+        seen += 1
+    assert seen == 5
+
+
+@pytest.mark.gpu
+def test_harness_epoch_loop_and_measurements(favit, tmp_path):
+    """fit / evaluate / measure_* on a tiny model and a synthetic uint8 dataset: the loss goes down, the result row
+    has the reference's columns (experiments/mhla_pretrained.py:486-525), timers return positive device times."""
+    D, Hh = favit.data, favit.harness
+    favit.set_compute_dtype("fp32")
+    torch.manual_seed(0)
+    rs = np.random.RandomState(1)
+    protos = rs.randint(0, 256, size=(4, 32, 32, 3))
+    def make(n):
+        y = rs.randint(0, 4, size=n)
+        x = np.clip(protos[y] + rs.randint(-20, 21, size=(n, 32, 32, 3)), 0, 255).astype(np.uint8)
+        return x, y
+    train = [make(32) for _ in range(6)]
+    test = [make(32) for _ in range(2)]
+    tfs = D.get_transforms("cifar10", 32, seed=0)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=4, embed_dim=64, depth=2,
+                                                    num_heads=4, use_mhla=True).to(DEV)
+    opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=3e-3), lr=3e-3, weight_decay=0.0, distributed=False)
+    res = Hh.fit(m, D.DeviceLoader(train, tfs["test"]), D.DeviceLoader(test, tfs["test"]), opt, epochs=6, log=lambda s: None)
+    h = res["history"]
+    assert h["train_loss"][-1] < 0.5 * h["train_loss"][0] and res["final_val_acc"] > 70.0
+    ev = Hh.evaluate(m, D.DeviceLoader(test, tfs["test"]))
+    assert set(ev) == {"test_loss", "test_acc", "avg_inference_time", "avg_inference_time_per_image"} and ev["avg_inference_time"] > 0
+    x = torch.randn(8, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 4, (8,), device=DEV)
+    ti = Hh.measure_inference_time(m, x, num_iterations=5, warm_up=2)
+    tt = Hh.measure_training_time(m, x, y, favit.train.cross_entropy, opt, num_iterations=3)
+    mem = Hh.measure_memory_usage(m, x, backward=True)
+    assert ti["fps"] > 0 and tt["iterations_per_second"] > 0 and mem["gpu_memory_peak_mb"] > 0
+    row = {"model": "ViT + MHLA", "avg_epoch_time": res["avg_epoch_time"], "total_training_time": res["total_training_time"],
+           "final_val_acc": res["final_val_acc"], "final_val_loss": res["final_val_loss"], "test_acc": ev["test_acc"],
+           "test_loss": ev["test_loss"], "avg_inference_time_per_image": ev["avg_inference_time_per_image"],
+           "peak_gpu_memory_mb": res["peak_gpu_memory_mb"]}
+    path = tmp_path / "results" / "exp.csv"
+    Hh.save_results_csv(str(path), row)
+    lines = path.read_text().strip().splitlines()
+    assert lines[0].split(",") == list(row.keys()) and len(lines) == 2
+    favit.functional.clear_lp_mirrors()

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""main.py-equivalent runner (the reference's main.py:64-149 cannot even be imported: three wrong
+import names, main.py:41-43).  Same argument names for the settings that concern the path; the dataset is either a
+.npz file {x_train uint8 [N,H,W,3], y_train, x_test, y_test} or a synthetic one (no downloads: there is no network).
+
+    python tools/run_experiment.py --experiment mhla --img_size 32 --patch_size 4 --embed_dim 64 --depth 2 \
+        --num_heads 4 --epochs 3 --batch_size 64 --results_dir gpurun_out/exp
+"""
+import argparse
+import importlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def synthetic_dataset(n, classes, size, seed):
+    rs = np.random.RandomState(seed)
+    protos = rs.randint(0, 256, size=(classes, size, size, 3))
+    y = rs.randint(0, classes, size=n)
+    x = np.clip(protos[y] + rs.randint(-40, 41, size=(n, size, size, 3)), 0, 255).astype(np.uint8)
+    return x, y
+
+
+def batches(x, y, bs, shuffle, rs):
+    idx = rs.permutation(len(x)) if shuffle else np.arange(len(x))
+    return [(x[idx[i:i + bs]], y[idx[i:i + bs]]) for i in range(0, len(x) - bs + 1, bs)]
+
+
+def main():
+    ap = argparse.ArgumentParser(description="Vision Transformer experiments on the MI355X hot path")
+    ap.add_argument("--experiment", required=True, choices=["traditional", "mhla", "sppp_mhla"])
+    ap.add_argument("--data", default=None, help=".npz dataset (default: synthetic)")
+    ap.add_argument("--dataset", default="cifar10", choices=["cifar10", "imagenet", "default"], help="transform stack")
+    ap.add_argument("--results_dir", default="./results")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--img_size", type=int, default=224)
+    ap.add_argument("--batch_size", type=int, default=64)
+    ap.add_argument("--patch_size", type=int, default=16)
+    ap.add_argument("--embed_dim", type=int, default=768)
+    ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--num_heads", type=int, default=12)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--num_superpixels", type=int, default=16)
+    ap.add_argument("--compactness", type=float, default=0.1)
+    ap.add_argument("--pooling_type", default="mean", choices=["mean", "max", "attention"])
+    ap.add_argument("--window_size", type=int, default=7)
+    ap.add_argument("--epochs", type=int, default=100)
+    ap.add_argument("--learning_rate", type=float, default=1e-4)
+    ap.add_argument("--weight_decay", type=float, default=0.05)
+    ap.add_argument("--head_learning_rate", type=float, default=1e-3)
+    ap.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32", "fp8"])
+    a = ap.parse_args()
+
+    pkg = importlib.import_module("focused-attention-vit_amd")
+    pkg.set_compute_dtype(a.compute_dtype)
+    torch.manual_seed(a.seed)
+    rs = np.random.RandomState(a.seed)
+    if a.data:
+        d = np.load(a.data, allow_pickle=False)
+        xtr, ytr, xte, yte = d["x_train"], d["y_train"], d["x_test"], d["y_test"]
+    else:
+        src = 32 if a.dataset == "cifar10" else a.img_size
+        xtr, ytr = synthetic_dataset(2048, 10, src, a.seed)
+        xte, yte = synthetic_dataset(512, 10, src, a.seed)       # same prototypes (same seed), fresh noise below
+        xte = np.clip(xte.astype(np.int32) + rs.randint(-10, 11, size=xte.shape), 0, 255).astype(np.uint8)
+    classes = int(max(ytr.max(), yte.max())) + 1
+    M = pkg.models
+    kw = dict(img_size=a.img_size, patch_size=a.patch_size, num_classes=classes, embed_dim=a.embed_dim, depth=a.depth,
+              num_heads=a.num_heads, dropout=a.dropout)
+    if a.experiment == "traditional":
+        model = M.vit.VisionTransformer(**kw)
+    elif a.experiment == "mhla":
+        model = M.vit_mhla.VisionTransformerMHLA(window_size=a.window_size, use_mhla=True, **kw)
+    else:
+        model = M.sppp_mhla.SPPPViTMHLA(num_superpixels=a.num_superpixels, pooling_type=a.pooling_type,
+                                        window_size=a.window_size, use_mhla=True, **kw)
+        model.segmentation.compactness = a.compactness
+    model = model.cuda()
+    tfs = pkg.data.get_transforms(a.dataset, a.img_size, seed=a.seed)
+    opt = pkg.train.FusedAdamW(pkg.train.param_groups(model, lr=a.learning_rate, head_lr=a.head_learning_rate),
+                               lr=a.learning_rate, weight_decay=a.weight_decay, distributed=False)
+
+    class Epochs:            # a fresh shuffle per epoch
+        def __init__(self, x, y, shuffle):
+            self.x, self.y, self.shuffle = x, y, shuffle
+        def __len__(self):
+            return len(self.x) // a.batch_size
+        def __iter__(self):
+            return iter(batches(self.x, self.y, a.batch_size, self.shuffle, rs))
+    train_loader = pkg.data.DeviceLoader(Epochs(xtr, ytr, True), tfs["train"])
+    test_loader = pkg.data.DeviceLoader(Epochs(xte, yte, False), tfs["test"])
+    res = pkg.harness.fit(model, train_loader, test_loader, opt, a.epochs)
+    ev = pkg.harness.evaluate(model, test_loader, a.batch_size)
+    row = {"model": a.experiment, "img_size": a.img_size, "patch_size": a.patch_size, "embed_dim": a.embed_dim, "depth": a.depth,
+           "num_heads": a.num_heads, "window_size": a.window_size, "total_parameters": sum(p.numel() for p in model.parameters()),
+           "avg_epoch_time": res["avg_epoch_time"], "total_training_time": res["total_training_time"],
+           "final_val_acc": res["final_val_acc"], "final_val_loss": res["final_val_loss"], "test_acc": ev["test_acc"],
+           "test_loss": ev["test_loss"], "avg_inference_time_per_image": ev["avg_inference_time_per_image"],
+           "peak_gpu_memory_mb": res["peak_gpu_memory_mb"]}
+    path = os.path.join(a.results_dir, f"exp_{a.experiment}.csv")
+    pkg.harness.save_results_csv(path, row)
+    print(f"Results saved to {path}")
+
+
+if __name__ == "__main__":
+    main()
