@@ -54,6 +54,8 @@ _SIGS = {
     "favit_strerror": ([C.c_int], C.c_char_p),
     "favit_gemm": ([C.POINTER(GemmDesc), vp], C.c_int),
     "favit_gemm_grouped_tn": ([C.POINTER(GemmDesc), i32, vp], C.c_int),
+    "favit_gemm_grouped_tn_workspace": ([C.POINTER(GemmDesc), i32], C.c_int64),
+    "favit_gemm_grouped_tn_ws": ([C.POINTER(GemmDesc), i32, vp, i64, vp], C.c_int),
     "favit_cast": ([vp, C.c_int, vp, C.c_int, i64, vp], C.c_int),
     "favit_fp8_amax": ([vp, C.c_int, i64, i64, i64, vp, vp], C.c_int),
     "favit_fp8_quantize": ([vp, C.c_int, i64, i64, i64, vp, i64, vp, i64, C.c_int, vp, vp, vp, vp], C.c_int),

@@ -64,6 +64,7 @@ struct KParams {
   int ntiles;          // output tiles per (split, batch)
   int xcd_split;       // 1: 1-D grid of ntiles*nsplit blocks, all tiles of a split on one XCD
   int store_policy;    // cache policy of the epilogue's output stores (store16_policy)
+  int rowsum_store;    // 1: a_rowsum is a private slab slot of this split (plain store), 0: atomicAdd
 #ifdef FAVIT_PROBE
   int dbg;     // probe build only (make probe; tools/): 1 = skip epilogue, 2 = skip main loop
   unsigned long long* probe;   // probe build only: per-wave cycle stamps of the pp kernel (favit_probe_buffer)
@@ -970,7 +971,10 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long m = m0 + wr * 64 + i * 16 + lane;
-      if (m < p.M) atomicAdd(p.a_rowsum + m, racc[i][0]);
+      if (m < p.M) {
+        if (p.rowsum_store) p.a_rowsum[m] = racc[i][0];       // exactly one tile column (n0 == 0) writes row m
+        else atomicAdd(p.a_rowsum + m, racc[i][0]);
+      }
     }
   }
 #ifdef FAVIT_PROBE
@@ -1449,6 +1453,7 @@ int launch_s64(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
 constexpr int GROUP_MAX = 8;
 struct GroupParams {
   int count, total_tiles, nsplit, pad_;
+  long slab_stride;    // floats between the partial-result slabs of consecutive K-splits (0: fp32 atomics into C)
   int tile_off[GROUP_MAX + 1];
   KParams p[GROUP_MAX];
 };
@@ -1459,7 +1464,51 @@ __global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_grouped_tn_kernel(
   const int t = idx % gp.total_tiles;
   int i = 0;
   while (i + 1 < gp.count && t >= gp.tile_off[i + 1]) ++i;
-  p4_body<false, false, float>(gp.p[i], t - gp.tile_off[i], split, 0);
+  if (gp.slab_stride == 0) {
+    p4_body<false, false, float>(gp.p[i], t - gp.tile_off[i], split, 0);
+  } else {
+    // slab mode: this split's partial tile goes to its own slab with plain 16-byte stores (no atomics)
+    KParams kp = gp.p[i];
+    kp.C = reinterpret_cast<float*>(kp.C) + (long)split * gp.slab_stride;
+    if (kp.a_rowsum) kp.a_rowsum += (long)split * gp.slab_stride;
+    p4_body<false, false, float>(kp, t - gp.tile_off[i], split, 0);
+  }
+}
+
+// Second half of the slab-mode split-K: dst = (accumulate ? dst : 0) + sum over the splits' slabs, in split order
+// (a fixed summation order: weight gradients are bitwise reproducible, unlike fp32 atomics).
+struct ReduceSeg {
+  float* dst;          // dW [rows, ld] or db [rows]
+  long off;            // offset of this segment inside a slab (floats)
+  long rows, cols, ld; // cols = 1, ld = 1 for a bias-gradient segment
+  int accumulate;
+};
+struct ReduceParams {
+  const float* ws;
+  long slab_stride;
+  int nsplit, nseg;
+  ReduceSeg seg[2 * GROUP_MAX];
+};
+
+__global__ __launch_bounds__(256) void grouped_reduce_kernel(ReduceParams rp) {
+  const ReduceSeg& sg = rp.seg[blockIdx.y];
+  const long n4 = sg.rows * sg.cols / 4;               // rows * cols is a multiple of 4 (host)
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+    const long e = 4 * q;
+    const float* src = rp.ws + sg.off + e;
+    float4 acc = *reinterpret_cast<const float4*>(src);
+    for (int sidx = 1; sidx < rp.nsplit; ++sidx) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (long)sidx * rp.slab_stride);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const long r = e / sg.cols, c = e - r * sg.cols;   // cols % 4 == 0 (or the segment is one contiguous vector)
+    float* d = sg.dst + r * sg.ld + c;
+    if (sg.accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(d);
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    *reinterpret_cast<float4*>(d) = acc;
+  }
 }
 
 template <typename Kn>
@@ -1781,6 +1830,7 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   // epilogue outputs / residual / aux reads are touched once: non-temporal keeps them from evicting
   // the operand panels the co-resident workgroups share in L2 (fc2: 140 -> 114 us)
   kp.store_policy = knobs().store_policy;
+  kp.rowsum_store = 0;
   if (g->dropout_p < 0.f || g->dropout_p >= 1.f) return FAVIT_ERR_INVALID;
   kp.drop_thresh = dropout_threshold(g->dropout_p);
   kp.drop_scale = 1.0f / (1.0f - g->dropout_p);
@@ -1947,7 +1997,28 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   }
 }
 
-extern "C" int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void* stream) {
+namespace {
+
+// slab layout shared by the size query and the launch: per problem the dense [M, N] partial, then its [M] bias row
+long grouped_slab_floats(const favit_gemm_t* gs, int count) {
+  long tot = 0;
+  for (int i = 0; i < count; ++i) tot += gs[i].M * gs[i].N + ((gs[i].M + 3) / 4) * 4;
+  return (tot + 63) / 64 * 64;
+}
+
+long grouped_nsplit(long total_tiles) {
+  // splits = 8*s: one group of s splits per XCD; pick s that fills the 64 slots of an XCD best
+  double best = -1.0;
+  long best_s = 1;
+  for (long s = 1; s <= 4; ++s) {
+    const long w = total_tiles * s;
+    const double util = (double)w / (double)(((w + 63) / 64) * 64);
+    if (util > best + 0.02) { best = util; best_s = s; }
+  }
+  return 8 * best_s;
+}
+
+int grouped_tn_impl(const favit_gemm_t* gs, int32_t count, float* ws, int64_t ws_bytes, void* stream) {
   if (!gs || count <= 0 || count > GROUP_MAX) return FAVIT_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   GroupParams gp;
@@ -1985,8 +2056,10 @@ extern "C" int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void
     kp.alpha = 1.0f;
     kp.drop_thresh = 0; kp.drop_scale = 1.0f; kp.drop_seed = 0;
     kp.store_policy = 0;
+    kp.rowsum_store = 0;
+    kp.scale_a = kp.scale_b = nullptr;
 #ifdef FAVIT_PROBE
-    kp.dbg = 0;
+    kp.dbg = knobs().dbg;            // probe build: FAVIT_GEMM_DBG=1 times the grouped main loop without its epilogue
     kp.probe = nullptr;
 #endif
     gp.tile_off[i] = off;
@@ -1994,31 +2067,77 @@ extern "C" int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void
   }
   gp.tile_off[count] = off;
   gp.total_tiles = off;
-  // splits = 8*s: one group of s splits per XCD; pick s that fills the 64 slots of an XCD best
-  double best = -1.0;
-  long best_s = 1;
-  for (long s = 1; s <= 4; ++s) {
-    const long w = (long)off * s;
-    const double util = (double)w / (double)(((w + 63) / 64) * 64);
-    if (util > best + 0.02) { best = util; best_s = s; }
-  }
-  long nsplit = 8 * best_s;
+  const long nsplit = grouped_nsplit(off);
   long kps = (K + nsplit - 1) / nsplit;
   kps = ((kps + P4_BK - 1) / P4_BK) * P4_BK;
   if ((nsplit - 1) * kps >= K) return FAVIT_ERR_UNSUPPORTED;       // too few tokens to split 8 ways
   gp.nsplit = (int)nsplit;
-  for (int i = 0; i < count; ++i) {
-    gp.p[i].k_per_split = kps;
-    if (!gs[i].accumulate) {
-      const long total = gs[i].M * gs[i].N;
-      const int zb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-      hipLaunchKernelGGL(zero_c_kernel, dim3(zb, 1, 1), dim3(256), 0, st, reinterpret_cast<float*>(gs[i].C), gs[i].M,
-                         gs[i].N, gs[i].ldc, 0L, 0L, 1);
-      FAVIT_CHECK_LAUNCH();
+  for (int i = 0; i < count; ++i) gp.p[i].k_per_split = kps;
+
+  const long stride = grouped_slab_floats(gs, count);
+  bool slabs = ws != nullptr && ws_bytes >= (int64_t)(nsplit * stride * 4) && aligned(ws, 16);
+  for (int i = 0; i < count; ++i)      // the reduction writes 16-byte vectors: unaligned destinations keep the atomic path
+    slabs = slabs && (gs[i].ldc % 4) == 0 && aligned(gs[i].C, 16) && (!gs[i].a_rowsum || aligned(gs[i].a_rowsum, 16));
+  gp.slab_stride = slabs ? stride : 0;
+  ReduceParams rp;
+  if (slabs) {
+    // Every split writes its partial tiles with plain 16-byte stores into its own slab; a second kernel adds the
+    // slabs in split order.  fp32 atomics reach ~1.3 TB/s chip-wide (MI355X_MICROARCH.md) against ~5 TB/s for plain
+    // stores + the reduction's reads: measured 318 -> 227 us main loop + epilogue at the cfg2 block shapes and
+    // 914 -> 538 us at ViT-Base (tools/grouped_probe.py), and the result no longer depends on arrival order.
+    rp.ws = ws; rp.slab_stride = stride; rp.nsplit = (int)nsplit; rp.nseg = 0;
+    long o = 0;
+    for (int i = 0; i < count; ++i) {
+      KParams& kp = gp.p[i];
+      rp.seg[rp.nseg++] = ReduceSeg{reinterpret_cast<float*>(gs[i].C), o, gs[i].M, gs[i].N, gs[i].ldc, gs[i].accumulate ? 1 : 0};
+      kp.C = ws + o;
+      kp.ldc = gs[i].N;
+      kp.atomic = 0;
+      kp.c_vec = 1;
+      o += gs[i].M * gs[i].N;
+      if (gs[i].a_rowsum) {
+        // the bias gradient is always ADDED to its destination (the fused column sum's contract); M % 8 == 0
+        rp.seg[rp.nseg++] = ReduceSeg{gs[i].a_rowsum, o, 1, gs[i].M, gs[i].M, 1};
+        kp.a_rowsum = ws + o;
+        kp.rowsum_store = 1;
+      }
+      o += ((gs[i].M + 3) / 4) * 4;
+    }
+  } else {
+    for (int i = 0; i < count; ++i) {
+      if (!gs[i].accumulate) {
+        const long total = gs[i].M * gs[i].N;
+        const int zb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(zero_c_kernel, dim3(zb, 1, 1), dim3(256), 0, st, reinterpret_cast<float*>(gs[i].C), gs[i].M,
+                           gs[i].N, gs[i].ldc, 0L, 0L, 1);
+        FAVIT_CHECK_LAUNCH();
+      }
     }
   }
   favit_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_p4_grouped_tn_kernel), P4_LDS);
   hipLaunchKernelGGL(gemm_bf16_p4_grouped_tn_kernel, dim3((unsigned)(off * nsplit)), dim3(P4_THREADS), P4_LDS, st, gp);
   FAVIT_CHECK_LAUNCH();
+  if (slabs) {
+    hipLaunchKernelGGL(grouped_reduce_kernel, dim3(512, (unsigned)rp.nseg), dim3(256), 0, st, rp);
+    FAVIT_CHECK_LAUNCH();
+  }
   return FAVIT_OK;
+}
+
+}  // namespace
+
+extern "C" int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void* stream) {
+  return grouped_tn_impl(gs, count, nullptr, 0, stream);
+}
+
+extern "C" int64_t favit_gemm_grouped_tn_workspace(const favit_gemm_t* gs, int32_t count) {
+  if (!gs || count <= 0 || count > GROUP_MAX) return 0;
+  long tiles = 0;
+  for (int i = 0; i < count; ++i) tiles += ((gs[i].M + P4_BM - 1) / P4_BM) * ((gs[i].N + BN - 1) / BN);
+  return (int64_t)(grouped_nsplit(tiles) * grouped_slab_floats(gs, count) * 4);
+}
+
+extern "C" int favit_gemm_grouped_tn_ws(const favit_gemm_t* gs, int32_t count, void* workspace, int64_t workspace_bytes,
+                                        void* stream) {
+  return grouped_tn_impl(gs, count, reinterpret_cast<float*>(workspace), workspace_bytes, stream);
 }

@@ -119,10 +119,15 @@ def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias
     GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, key, (M, N, K, batch)))
 
 
-def gemm_grouped_tn(problems) -> bool:
+_GROUPED_WS = {}          # device index -> workspace tensor of the slab-mode split-K reduction
+
+
+def gemm_grouped_tn(problems, use_workspace: bool = True) -> bool:
     """One launch for several weight-gradient GEMMs dW = dY^T X that share the token dim.
     problems: list of (dy [T,N], a [T,K], dw [N,K] fp32, db [N] fp32 or None, accumulate: bool).
-    Returns False if the library cannot group them (caller falls back to single launches)."""
+    Returns False if the library cannot group them (caller falls back to single launches).
+    use_workspace: partial results of the K-splits go through a cached device workspace and are summed in a fixed
+    order (deterministic, no fp32 atomics); False keeps the atomic path."""
     n = len(problems)
     if n == 0:
         return True
@@ -145,7 +150,16 @@ def gemm_grouped_tn(problems) -> bool:
     if GEMM_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = _abi.lib().favit_gemm_grouped_tn(arr, n, _st())
+    if use_workspace:
+        need = int(_abi.lib().favit_gemm_grouped_tn_workspace(arr, n))
+        dev = problems[0][0].device
+        ws = _GROUPED_WS.get(dev.index)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+            _GROUPED_WS[dev.index] = ws
+        rc = _abi.lib().favit_gemm_grouped_tn_ws(arr, n, _p(ws), ws.numel(), _st())
+    else:
+        rc = _abi.lib().favit_gemm_grouped_tn(arr, n, _st())
     if rc == -2:
         return False
     _abi.check(rc, "favit_gemm_grouped_tn")

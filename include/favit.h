@@ -106,6 +106,13 @@ int favit_gemm(const favit_gemm_t* g, void* stream);
  * a_rowsum (bias gradient) and accumulate; returns FAVIT_ERR_UNSUPPORTED otherwise (the caller
  * then issues them one by one). */
 int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void* stream);
+/* The same launch with a caller-provided device workspace of favit_gemm_grouped_tn_workspace(gs, count) bytes:
+ * every K-split writes its partial results to a slab of the workspace with plain stores and a second kernel adds
+ * the slabs in a fixed order (no fp32 atomics: faster -- atomics run at ~1.3 TB/s chip-wide -- and bitwise
+ * reproducible).  A NULL / too small workspace falls back to the atomic path. */
+int64_t favit_gemm_grouped_tn_workspace(const favit_gemm_t* gs, int32_t count);
+int favit_gemm_grouped_tn_ws(const favit_gemm_t* gs, int32_t count, void* workspace, int64_t workspace_bytes,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------
  * FP8 operand preparation (BASELINE.json configs[3] "fp8 MFMA path"; no reference counterpart:

@@ -57,17 +57,34 @@ def _block_problems(T, gen, accumulate):
     return probs, refs
 
 
+@pytest.mark.parametrize("slabs", [True, False])
 @pytest.mark.parametrize("accumulate", [False, True])
 @pytest.mark.parametrize("T", [512, 2048 + 32, T_BENCH])
-def test_gemm_grouped_tn_block_problems(K, T, accumulate):
+def test_gemm_grouped_tn_block_problems(K, T, accumulate, slabs):
+    """slabs: the split-K partials go through the workspace and are summed in a fixed order (the product path);
+    not slabs: fp32 atomics into the destination (the fallback without a workspace)."""
     gen = torch.Generator(device=DEV).manual_seed(T + int(accumulate))
     probs, refs = _block_problems(T, gen, accumulate)
-    assert K.gemm_grouped_tn(probs), "the grouped launch must accept the block's four problems at T %% 32 == 0"
+    assert K.gemm_grouped_tn(probs, use_workspace=slabs), "the grouped launch must accept the block's four problems at T %% 32 == 0"
     torch.cuda.synchronize()
     for (dy, x, dw, db, _), (ref_w, ref_b) in zip(probs, refs):
         assert torch.isfinite(dw).all()
         assert rel_l2(dw, ref_w) < 2e-5, (tuple(dw.shape), rel_l2(dw, ref_w))
         assert rel_l2(db, ref_b) < 2e-5, (tuple(dw.shape), rel_l2(db, ref_b))
+
+
+def test_gemm_grouped_tn_slab_reduction_is_deterministic(K):
+    """Weight gradients through the workspace are bitwise reproducible (fixed summation order); through fp32
+    atomics they are not guaranteed to be."""
+    outs = []
+    for _ in range(3):
+        gen = torch.Generator(device=DEV).manual_seed(11)
+        probs, _ = _block_problems(T_BENCH, gen, False)
+        assert K.gemm_grouped_tn(probs)
+        outs.append([(p[2].clone(), p[3].clone()) for p in probs])
+    for o in outs[1:]:
+        for (w0, b0), (w1, b1) in zip(outs[0], o):
+            assert torch.equal(w0, w1) and torch.equal(b0, b1)
 
 
 def test_gemm_grouped_tn_declines_what_it_cannot_group(K):
