@@ -111,6 +111,25 @@ __device__ __forceinline__ float dpp_sum8(float v) {
   return v;
 }
 
+// Exchange with lane ^ 16 / lane ^ 32 in the VALU (gfx950 v_permlane16_swap / v_permlane32_swap: the odd rows of
+// the first operand are swapped with the even rows of the second).  __shfl_xor(v, 16) compiles to ds_bpermute_b32,
+// a round trip through the LDS crossbar (~100 cycles of dependent latency per reduction step in the softmax).
+__device__ __forceinline__ float lane_xor16(float v) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  const unsigned u = __float_as_uint(v);
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(((threadIdx.x >> 4) & 1) ? r.x : r.y);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  const unsigned u = __float_as_uint(v);
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(((threadIdx.x >> 5) & 1) ? r.x : r.y);
+}
+// reductions over the four lanes {l, l^16, l^32, l^48} (the 4 k-slices of one MFMA column)
+__device__ __forceinline__ float quad16_max(float v) { v = fmaxf(v, lane_xor16(v)); return fmaxf(v, lane_xor32(v)); }
+__device__ __forceinline__ float quad16_sum(float v) { v += lane_xor16(v); return v + lane_xor32(v); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

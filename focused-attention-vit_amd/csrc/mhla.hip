@@ -216,6 +216,41 @@ struct RowStager {
   }
 };
 
+// Two matrices staged with ONE row mapping (K~ and V~ share their rows, Q and dO theirs): the slot -> row index
+// arithmetic and the chunk offsets are computed once per 16-byte chunk instead of once per matrix (these kernels
+// are bound by their VALU instruction count, not by memory).
+template <typename T, int NCH>
+struct PairStager {
+  uint4 ra[NCH], rb[NCH];
+  template <typename F>
+  __device__ __forceinline__ void load(int nrows, const T* srcA, long ldA, int colA, const T* srcB, long ldB, int colB,
+                                       long tok0, int hd, int tid, F row_of) {
+    const int cpr = hd * (int)sizeof(T) / 16;
+    const int total = nrows * cpr;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int c = min(tid + 256 * it, total - 1);      // clamped: unconditional load, store is predicated
+      const int s = c / cpr, ch = c - s * cpr;
+      const long row = tok0 + row_of(s);
+      ra[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(srcA + row * ldA + colA) + ch * 16);
+      rb[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(srcB + row * ldB + colB) + ch * 16);
+    }
+  }
+  __device__ __forceinline__ void store(char* ldsA, char* ldsB, int nrows, int hd, int rs, int tid) const {
+    const int cpr = hd * (int)sizeof(T) / 16;
+    const int total = nrows * cpr;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int c = tid + 256 * it;
+      if (c < total) {
+        const int s = c / cpr, ch = c - s * cpr;
+        *reinterpret_cast<uint4*>(ldsA + s * rs + ch * 16) = ra[it];
+        *reinterpret_cast<uint4*>(ldsB + s * rs + ch * 16) = rb[it];
+      }
+    }
+  }
+};
+
 struct AttnArgs {
   const void* qkv;
   const void* dout;
@@ -511,7 +546,7 @@ __device__ __forceinline__ int slot_key(int slot, int t0, int h, int L) {
   return min(max(j, 0), L - 1);
 }
 
-template <int HD>
+template <int HD, bool PLAIN>            // PLAIN: no mask, no dropout (compiled out)
 __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = HD * 2 + 16;                      // padded row: conflict-free fragment reads
@@ -529,12 +564,10 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
   char* ldsV = smem + im.n_rows * RS;
   {
     constexpr int NCH = (80 * (HD * 2 / 16) + 255) / 256;
-    RowStager<bf16_t, NCH> sk, sv;
+    PairStager<bf16_t, NCH> skv;
     auto rowf = [&](int s) { return im.row_of_slot(s); };
-    sk.load(im.n_rows, qkv, ld, tok0, D + head * HD, HD, tid, rowf);
-    sv.load(im.n_rows, qkv, ld, tok0, 2 * D + head * HD, HD, tid, rowf);
-    sk.store(ldsK, im.n_rows, HD, RS, tid);
-    sv.store(ldsV, im.n_rows, HD, RS, tid);
+    skv.load(im.n_rows, qkv, ld, D + head * HD, qkv, ld, 2 * D + head * HD, tok0, HD, tid, rowf);
+    skv.store(ldsK, ldsV, im.n_rows, HD, RS, tid);
   }
   __syncthreads();
 
@@ -581,9 +614,9 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
     } else {
       j = 0; mu = 0; w0 = 0;
     }
-    if (mu > 0 && a.mask && a.mask[((long)b * L + si.i) * L + j] == 0) mu = 0;     // mhla.py:143
+    if (!PLAIN && mu > 0 && a.mask && a.mask[((long)b * L + si.i) * L + j] == 0) mu = 0;     // mhla.py:143
     float kwe = (float)mu;
-    if (a.thresh && mu > 0) {                            // dropout acts on every window copy separately
+    if (!PLAIN && a.thresh && mu > 0) {                            // dropout acts on every window copy separately
       kwe = 0.f;
       for (int c = 0; c < mu; ++c) {
         const uint64_t idx = (((uint64_t)b * a.H + head) * L + si.i) * W + (w0 + c);
@@ -595,16 +628,14 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
     kw[e] = kwe;
     if (mu > 0) mx = fmaxf(mx, sc[e]);
   }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  mx = quad16_max(mx);
   float lsum = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     sc[e] = (mult[e] > 0.f) ? __expf(sc[e] - mx) : 0.f;
     lsum = fmaf(mult[e], sc[e], lsum);
   }
-  lsum += __shfl_xor(lsum, 16, 64);
-  lsum += __shfl_xor(lsum, 32, 64);
+  lsum = quad16_sum(lsum);
   const float inv_l = 1.0f / lsum;
   bf16x8 pf;
 #pragma unroll
@@ -760,16 +791,14 @@ __global__ __launch_bounds__(256) void mhla_bwd_mfma_kernel(AttnArgs a) {
       kw[e] = kwe;
       if (mu > 0) mx = fmaxf(mx, sc[e]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = quad16_max(mx);
     float lsum = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       sc[e] = (mult[e] > 0.f) ? __expf(sc[e] - mx) : 0.f;
       lsum = fmaf(mult[e], sc[e], lsum);
     }
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
+    lsum = quad16_sum(lsum);
     const float inv_l = 1.0f / lsum;
     float dot = 0.f;
     float dpn[8];
@@ -779,8 +808,7 @@ __global__ __launch_bounds__(256) void mhla_bwd_mfma_kernel(AttnArgs a) {
       dpn[e] = kw[e] * dP[e >> 2][e & 3];
       dot = fmaf(sc[e], dpn[e], dot);
     }
-    dot += __shfl_xor(dot, 16, 64);
-    dot += __shfl_xor(dot, 32, 64);
+    dot = quad16_sum(dot);
     bf16x8 dsf;
     bf16x4 pw0, pw1, ds0, ds1;
 #pragma unroll
@@ -886,6 +914,329 @@ __global__ __launch_bounds__(256) void mhla_bwd_mfma_kernel(AttnArgs a) {
     dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qq), wds, dk, 0, 0, 0);
     dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gg), wp, dv, 0, 0, 0);
     if (jvalid) {
+      bf16x4 kb4 = {(bf16_t)dk[0], (bf16_t)dk[1], (bf16_t)dk[2], (bf16_t)dk[3]};
+      bf16x4 vb4 = {(bf16_t)dv[0], (bf16_t)dv[1], (bf16_t)dv[2], (bf16_t)dv[3]};
+      *reinterpret_cast<bf16x4*>(dkrow + 16 * dt + 4 * g) = kb4;
+      *reinterpret_cast<bf16x4*>(dvrow + 16 * dt + 4 * g) = vb4;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// MFMA backward, second formulation ("two owner passes", bf16, hd in {32,64,128}, W <= 11): no dS / P tables.
+// A workgroup owns `rb` (<= 64, balanced over L) consecutive rows as QUERIES and as KEYS; four waves, one
+// 16-row tile each per pass.
+//   pass 1 (owner = 16 queries, 32 key slots, as the forward): S and dP = dO.V^T on MFMA, softmax with the slot
+//           multiplicities, dS -> dQ^T = K_slots^T . dS for the rows the block owns.  Every query tile the block's
+//           keys can see (its own rows, the h halo rows on each side, the wrap rows of keys 0 / L-1) leaves only
+//           two numbers per row in LDS: lse_i and delta_i = sum_w P_w dP_w.
+//   pass 2 (owner = 16 keys, 32 QUERY slots: the 16 + 2h band queries plus the wrap rows): S^T and dP^T are
+//           RECOMPUTED on MFMA from the staged Q / dO rows (8 MFMAs at hd = 64 -- cheaper than keeping two
+//           [rows][32] tables in LDS and gathering them), P = mult * exp(s - lse_i), dS = P (kw dP - mult
+//           delta_i); dK^T = Q_slots^T . dS and dV^T = dO_slots^T . Pd with ds_read_b64_tr_b16 fragments.
+// LDS: K~, V~ rows [r0 - 2h, r1 + 2h) + edges, Q, dO query tiles, 8 bytes of statistics per query row: 50 KiB at
+// L = 197, W = 7, hd = 64 (three workgroups per CU; the table formulation needed 72 KiB -> two).
+// Deterministic (no atomics); halo rows are recomputed.
+// ---------------------------------------------------------------------------------
+// PLAIN: no mask and no dropout (the training configurations of BASELINE.json): the per-element mask loads and
+// dropout draws are compiled out.
+template <int HD, bool PLAIN>
+__global__ __launch_bounds__(256) void mhla_bwd_mfma2_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RS = HD * 2 + 16;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, qi = lane & 15, q4 = qi >> 2, p4 = qi & 3;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int r0 = blockIdx.x * a.rb, r1 = min(a.L, r0 + a.rb);
+  const int L = a.L, W = a.W, h = W >> 1, D = a.H * HD;
+  const long ld = 3L * D, tok0 = (long)b * L;
+  const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
+  const bf16_t* dout = reinterpret_cast<const bf16_t*>(a.dout);
+  bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.out);
+
+  // query tiles: main rows [qm_lo, qm_hi) in tiles of 16, then (if this block owns key L-1) the rows 0.. that
+  // END-pad onto it, then (if it owns key 0) the rows tx_lo.. that FRONT-pad onto it
+  const int qm_lo = max(0, r0 - h), qm_hi = min(L, r1 + h);
+  const int nmt = (qm_hi - qm_lo + 15) >> 4;
+  const int has_hx = (r1 >= L) ? 1 : 0;
+  const int tx_lo = max(h + 1, L - h);
+  const int has_tx = (r0 == 0 && tx_lo < L) ? 1 : 0;
+  const int ntiles = nmt + has_hx + has_tx;
+  auto tile_t0 = [&](int t) { return t < nmt ? qm_lo + 16 * t : ((has_hx && t == nmt) ? 0 : tx_lo); };
+  auto main_slot = [&](int i) { return min(max(i, qm_lo), qm_hi - 1) - qm_lo; };
+  auto row_slot = [&](int i, bool head_kind) {           // image / statistics slot of a wrap row
+    if (i >= qm_lo && i < qm_hi) return i - qm_lo;
+    return head_kind ? 16 * nmt + i : 16 * (nmt + has_hx) + (i - tx_lo);
+  };
+
+  RowImage imK;
+  imK.init(r0 - 2 * h, r1 + 2 * h, 2 * h + 1, L);
+  char* ldsK = smem;
+  char* ldsV = ldsK + imK.n_rows * RS;
+  char* ldsQ = ldsV + imK.n_rows * RS;
+  char* ldsG = ldsQ + 16 * ntiles * RS;
+  float* stat = reinterpret_cast<float*>(ldsG + 16 * ntiles * RS);      // [16*ntiles][2]: lse, delta
+
+  {
+    constexpr int CPR = HD * 2 / 16;
+    constexpr int NKV = (108 * CPR + 255) / 256, NQ = (112 * CPR + 255) / 256;
+    PairStager<bf16_t, NKV> skv;
+    PairStager<bf16_t, NQ> sqg;
+    auto rowk = [&](int s) { return imK.row_of_slot(s); };
+    auto rowq = [&](int s) { return min(tile_t0(s >> 4) + (s & 15), L - 1); };
+    skv.load(imK.n_rows, qkv, ld, D + head * HD, qkv, ld, 2 * D + head * HD, tok0, HD, tid, rowk);
+    sqg.load(16 * ntiles, qkv, ld, head * HD, dout, (long)D, head * HD, tok0, HD, tid, rowq);
+    skv.store(ldsK, ldsV, imK.n_rows, HD, RS, tid);
+    sqg.store(ldsQ, ldsG, 16 * ntiles, HD, RS, tid);
+  }
+  __syncthreads();
+#ifdef FAVIT_PROBE
+  if (a.dbg & 2) return;                                 // probe: staging only
+  const bool probe_nostore = (a.dbg & 1) != 0;
+#else
+  constexpr bool probe_nostore = false;
+#endif
+
+  const float inv_sq = 1.0f / sqrtf((float)HD);
+  // ---------------- pass 1: query tiles ----------------
+  for (int tile = wave; tile < ntiles; tile += 4) {
+    const int t0 = tile_t0(tile);
+    const int i = t0 + qi;
+    SlotInfo si;
+    si.init(min(i, L - 1), L, W, h);
+    const int krow0 = imK.slot_safe(slot_key(qi, t0, h, L)), krow1 = imK.slot_safe(slot_key(16 + qi, t0, h, L));
+    const char* qimg = ldsQ + (16 * tile + qi) * RS;
+    const char* gimg = ldsG + (16 * tile + qi) * RS;
+    f32x4 S[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 dP[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      const int off = (32 * ks + 8 * g) * 2;
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qimg + off);
+      const bf16x8 gf = *reinterpret_cast<const bf16x8*>(gimg + off);
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(ldsK + krow0 * RS + off);
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(ldsK + krow1 * RS + off);
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(ldsV + krow0 * RS + off);
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(ldsV + krow1 * RS + off);
+      S[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, S[0], 0, 0, 0);
+      S[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, S[1], 0, 0, 0);
+      dP[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, gf, dP[0], 0, 0, 0);
+      dP[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, gf, dP[1], 0, 0, 0);
+    }
+    float sc[8], mult[8], kw[8];
+    float mx = -INFINITY;
+    // interior tile (wave-uniform): every row has its full window of W distinct keys, no wrap slots, no padding
+    const bool interior = PLAIN && tile < nmt && t0 >= h && t0 + 15 + h <= L - 1;
+    if (interior) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int slot = 16 * (e >> 2) + 4 * g + (e & 3);
+        const int d = slot - h - qi;                                    // key - query
+        const bool in = (slot < 16 + 2 * h) && (d >= -h) && (d <= h);
+        sc[e] = S[e >> 2][e & 3] * inv_sq;
+        mult[e] = in ? 1.f : 0.f;
+        kw[e] = mult[e];
+        if (in) mx = fmaxf(mx, sc[e]);
+      }
+    } else {
+  #pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kt = e >> 2, r = e & 3;
+        const int slot = 16 * kt + 4 * g + r;
+        int j, mu, w0;
+        if (slot < 16 + 2 * h && slot < 30) {
+          j = t0 - h + slot;
+          mu = (j >= si.lo && j < si.hi) ? 1 : 0;
+          w0 = (si.lo == 0 || si.pad == 0) ? (j - si.lo) : si.pad + (j - si.lo);
+        } else if (slot == 30) {
+          j = 0; mu = si.front_pad; w0 = 0;
+        } else if (slot == 31) {
+          j = L - 1; mu = si.end_pad; w0 = si.n;
+        } else {
+          j = 0; mu = 0; w0 = 0;
+        }
+        if (!PLAIN && mu > 0 && a.mask && a.mask[((long)b * L + si.i) * L + j] == 0) mu = 0;
+        float kwe = (float)mu;
+        if (!PLAIN && a.thresh && mu > 0) {
+          kwe = 0.f;
+          for (int c = 0; c < mu; ++c) {
+            const uint64_t idx = (((uint64_t)b * a.H + head) * L + si.i) * W + (w0 + c);
+            kwe += favit_keep(a.seed, idx, a.thresh) ? a.keep_scale : 0.f;
+          }
+        }
+        sc[e] = S[kt][r] * inv_sq;
+        mult[e] = (float)mu;
+        kw[e] = kwe;
+        if (mu > 0) mx = fmaxf(mx, sc[e]);
+      }
+    }
+    mx = quad16_max(mx);
+    float lsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = (mult[e] > 0.f) ? __expf(sc[e] - mx) : 0.f;
+      lsum = fmaf(mult[e], sc[e], lsum);
+    }
+    lsum = quad16_sum(lsum);
+    const float inv_l = 1.0f / lsum;
+    float dot = 0.f;
+    float dpn[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] *= inv_l;                                   // single-copy probability
+      dpn[e] = kw[e] * dP[e >> 2][e & 3];
+      dot = fmaf(sc[e], dpn[e], dot);
+    }
+    dot = quad16_sum(dot);
+    if (g == 0) {
+      stat[2 * (16 * tile + qi)] = mx + __logf(lsum);
+      stat[2 * (16 * tile + qi) + 1] = dot;
+    }
+    // dQ^T = K_slots^T . dS  -- only for main tiles that contain rows this block owns
+    if (tile < nmt && t0 + 15 >= r0 && t0 < r1) {
+      bf16x8 dsf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsf[e] = (bf16_t)((sc[e] * dpn[e] - mult[e] * sc[e] * dot) * inv_sq);
+      const bool own = i >= r0 && i < r1;
+      const int vrow0 = imK.slot_safe(slot_key(4 * g + q4, t0, h, L)), vrow1 = imK.slot_safe(slot_key(16 + 4 * g + q4, t0, h, L));
+      bf16_t* dqrow = dqkv + (tok0 + si.i) * ld + head * HD;
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + vrow0 * RS + (16 * dt + 4 * p4) * 2));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + vrow1 * RS + (16 * dt + 4 * p4) * 2));
+        s16x8 kk;
+        kk[0] = lo4[0]; kk[1] = lo4[1]; kk[2] = lo4[2]; kk[3] = lo4[3];
+        kk[4] = hi4[0]; kk[5] = hi4[1]; kk[6] = hi4[2]; kk[7] = hi4[3];
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kk), dsf, o, 0, 0, 0);
+        if (own && !(probe_nostore && o[0] != 12345.f)) {
+          bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+          *reinterpret_cast<bf16x4*>(dqrow + 16 * dt + 4 * g) = ob;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- pass 2: key tiles ----------------
+  const int k0 = r0 + 16 * wave;
+  if (k0 >= r1) return;
+  const int j = k0 + qi;                                  // this lane's key (B-operand column)
+  const int jc = min(j, L - 1);
+  const bool has0 = (k0 == 0), hasL = (L - 1 >= k0 && L - 1 < k0 + 16);
+  const int nband = 16 + 2 * h;
+  const int nhx = hasL ? min(h, L - 1) + 1 : 0;           // rows 0..min(h,L-1) END-pad onto key L-1
+  // query slot -> (query row, image / statistics slot, kind): 0 band, 1 END-pad row, 2 FRONT-pad row, 3 unused
+  auto qs_row = [&](int qs, int& row, int& tslot, int& kind) {
+    if (qs < nband) {
+      kind = 0;
+      row = k0 - h + qs;
+      tslot = main_slot(row);
+    } else if (qs < nband + nhx) {
+      kind = 1;
+      row = qs - nband;
+      tslot = row_slot(row, true);
+    } else {
+      kind = 2;
+      row = tx_lo + (qs - nband - nhx);
+      if (!has0 || row >= L) { kind = 3; row = 0; tslot = main_slot(k0); return; }
+      tslot = row_slot(row, false);
+    }
+  };
+  const bool interior_keys = PLAIN && !has0 && !hasL;       // wave-uniform: band query slots only, multiplicity 0 / 1
+  auto img_slot = [&](int qs) {                             // Q / dO image row (and statistics slot) of a query slot
+    if (interior_keys) return main_slot(k0 - h + qs);       // (clamped: slots past the band carry multiplicity 0)
+    int row, tslot, kind;
+    qs_row(qs, row, tslot, kind);
+    return tslot;
+  };
+  // S^T[qs][key] = Q_qs . K_key,  dP^T[qs][key] = dO_qs . V_key   (A = the query slot rows, B = this lane's key row)
+  f32x4 T1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  f32x4 T2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  {
+    const int ts0 = img_slot(qi), ts1 = img_slot(16 + qi);
+    const char* kimg = ldsK + imK.slot_safe(jc) * RS;
+    const char* vimg = ldsV + imK.slot_safe(jc) * RS;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      const int off = (32 * ks + 8 * g) * 2;
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimg + off);
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vimg + off);
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(ldsQ + ts0 * RS + off);
+      const bf16x8 qb = *reinterpret_cast<const bf16x8*>(ldsQ + ts1 * RS + off);
+      const bf16x8 ga = *reinterpret_cast<const bf16x8*>(ldsG + ts0 * RS + off);
+      const bf16x8 gb = *reinterpret_cast<const bf16x8*>(ldsG + ts1 * RS + off);
+      T1[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, T1[0], 0, 0, 0);
+      T1[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb, kf, T1[1], 0, 0, 0);
+      T2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, vf, T2[0], 0, 0, 0);
+      T2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb, vf, T2[1], 0, 0, 0);
+    }
+  }
+  // the lane holds query slots 16 st + 4g + r (e = 4 st + r) of its key: exactly the k-slice of the next MFMAs
+  bf16x8 wds, wp;
+  if (interior_keys) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int qs = 16 * (e >> 2) + 4 * g + (e & 3);
+      const int row = k0 - h + qs, d = qs - h - qi;                    // query row, query - key
+      const int tslot = min(max(row, qm_lo), qm_hi - 1) - qm_lo;
+      const bool in = (qs < nband) && (row < L) && (j < L) && (d >= -h) && (d <= h);
+      const float lse = stat[2 * tslot], dl = stat[2 * tslot + 1];
+      const float pn = in ? __expf(T1[e >> 2][e & 3] * inv_sq - lse) : 0.f;
+      wds[e] = (bf16_t)(pn * (T2[e >> 2][e & 3] - dl) * inv_sq);
+      wp[e] = (bf16_t)pn;
+    }
+  } else {
+  #pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int row, tslot, kind;
+      qs_row(16 * (e >> 2) + 4 * g + (e & 3), row, tslot, kind);
+      int mu = 0, w0 = 0;
+      if (j < L && row >= 0 && row < L && kind != 3) {
+        const int lo = max(0, row - h), hi = min(L, row + h + 1), n = hi - lo, pad = W - n;
+        if (kind == 0) {
+          if (j >= lo && j < hi) { mu = 1; w0 = (lo == 0 || pad == 0) ? (j - lo) : pad + (j - lo); }
+        } else if (kind == 1) {
+          if (j == L - 1 && lo == 0) { mu = pad; w0 = n; }              // END padding of the rows whose window starts at 0
+        } else {
+          if (j == 0 && lo > 0) { mu = pad; w0 = 0; }                   // FRONT padding
+        }
+        if (!PLAIN && mu > 0 && a.mask && a.mask[((long)b * L + row) * L + j] == 0) mu = 0;
+      }
+      float kwe = (float)mu;
+      if (!PLAIN && a.thresh && mu > 0) {
+        kwe = 0.f;
+        for (int c = 0; c < mu; ++c) {
+          const uint64_t idx = (((uint64_t)b * a.H + head) * L + row) * W + (w0 + c);
+          kwe += favit_keep(a.seed, idx, a.thresh) ? a.keep_scale : 0.f;
+        }
+      }
+      const float lse = stat[2 * tslot], dl = stat[2 * tslot + 1];
+      const float pn = mu > 0 ? __expf(T1[e >> 2][e & 3] * inv_sq - lse) : 0.f;
+      wds[e] = (bf16_t)(pn * (kwe * T2[e >> 2][e & 3] - (float)mu * dl) * inv_sq);
+      wp[e] = (bf16_t)(pn * kwe);
+    }
+  }
+  // A fragments: Q^T / dO^T rows of query slots 4g+q4 and 16+4g+q4 (every lane supplies one row address)
+  const int ta = img_slot(4 * g + q4), tb = img_slot(16 + 4 * g + q4);
+  const bool jvalid = j < r1;
+  bf16_t* dkrow = dqkv + (tok0 + jc) * ld + D + head * HD;
+  bf16_t* dvrow = dkrow + D;
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) {
+    const int coff = (16 * dt + 4 * p4) * 2;
+    const s16x4 qa = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsQ + ta * RS + coff));
+    const s16x4 qb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsQ + tb * RS + coff));
+    const s16x4 ga = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsG + ta * RS + coff));
+    const s16x4 gb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsG + tb * RS + coff));
+    s16x8 qq, gg;
+    qq[0] = qa[0]; qq[1] = qa[1]; qq[2] = qa[2]; qq[3] = qa[3]; qq[4] = qb[0]; qq[5] = qb[1]; qq[6] = qb[2]; qq[7] = qb[3];
+    gg[0] = ga[0]; gg[1] = ga[1]; gg[2] = ga[2]; gg[3] = ga[3]; gg[4] = gb[0]; gg[5] = gb[1]; gg[6] = gb[2]; gg[7] = gb[3];
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qq), wds, dk, 0, 0, 0);
+    dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gg), wp, dv, 0, 0, 0);
+    if (jvalid && !(probe_nostore && dk[0] != 12345.f)) {
       bf16x4 kb4 = {(bf16_t)dk[0], (bf16_t)dk[1], (bf16_t)dk[2], (bf16_t)dk[3]};
       bf16x4 vb4 = {(bf16_t)dv[0], (bf16_t)dv[1], (bf16_t)dv[2], (bf16_t)dv[3]};
       *reinterpret_cast<bf16x4*>(dkrow + 16 * dt + 4 * g) = kb4;
@@ -1177,38 +1528,61 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
     const int h = W / 2;
     const size_t lds = (size_t)2 * (64 + 2 * h + 2) * (hd * 2 + 16);
     dim3 grid((L + 63) / 64, H, B);
-    if (hd == 32) hipLaunchKernelGGL(mhla_fwd_mfma_kernel<32>, grid, dim3(256), lds, st, a);
-    else if (hd == 64) hipLaunchKernelGGL(mhla_fwd_mfma_kernel<64>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(mhla_fwd_mfma_kernel<128>, grid, dim3(256), lds, st, a);
+    const bool plain = (mask == nullptr) && (a.thresh == 0);
+    if (hd == 32) { if (plain) hipLaunchKernelGGL((mhla_fwd_mfma_kernel<32, true>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((mhla_fwd_mfma_kernel<32, false>), grid, dim3(256), lds, st, a); }
+    else if (hd == 64) { if (plain) hipLaunchKernelGGL((mhla_fwd_mfma_kernel<64, true>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((mhla_fwd_mfma_kernel<64, false>), grid, dim3(256), lds, st, a); }
+    else { if (plain) hipLaunchKernelGGL((mhla_fwd_mfma_kernel<128, true>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((mhla_fwd_mfma_kernel<128, false>), grid, dim3(256), lds, st, a); }
     FAVIT_CHECK_LAUNCH();
     return FAVIT_OK;
   }
-  // The MFMA backward is correct (same tests as the default path) but measured slower than the
-  // 8-lanes-per-row kernel at the bench shape (189 vs 150 us: 72 KiB of LDS allow only two
-  // workgroups per CU and every phase is latency-bound), so it is opt-in: FAVIT_MHLA_BWD_MFMA=1.
+  // bf16 backward on MFMA, "two owner passes" formulation (mhla_bwd_mfma2_kernel): balanced row blocks of <= 64,
+  // no dS / P tables.  FAVIT_MHLA_BWD_TABLES selects the older table formulation (72 KiB of LDS), FAVIT_MHLA_VALU
+  // the 8-lanes-per-row kernel; all three pass the same tests.
   if (bwd && dtype == FAVIT_BF16 && (hd == 32 || hd == 64 || hd == 128) && (W <= 7 || (W <= 11 && L > 16)) &&
-      getenv("FAVIT_MHLA_BWD_MFMA") != nullptr && getenv("FAVIT_MHLA_VALU") == nullptr) {
+      getenv("FAVIT_MHLA_VALU") == nullptr && getenv("FAVIT_MHLA_BWD_MFMA") == nullptr && getenv("FAVIT_MHLA_BWD_TABLES") == nullptr) {
     const int h = W / 2;
     const int rs = hd * 2 + 16;
-    const int krows = (64 + 4 * h) + 2 * (2 * h + 1);
-    const int ntl = (64 + 2 * h + 15) / 16 + 2;
-    const size_t lds = (size_t)2 * krows * rs + (size_t)2 * 16 * ntl * rs + (size_t)2 * 16 * ntl * 32 * 2;
-    if (lds <= 160 * 1024) {
-      dim3 grid((L + 63) / 64, H, B);
-      if (hd == 32) {
-        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mhla_bwd_mfma_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(mhla_bwd_mfma_kernel<32>, grid, dim3(256), lds, st, a);
-      } else if (hd == 64) {
-        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mhla_bwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(mhla_bwd_mfma_kernel<64>, grid, dim3(256), lds, st, a);
-      } else {
-        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mhla_bwd_mfma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(mhla_bwd_mfma_kernel<128>, grid, dim3(256), lds, st, a);
-      }
+    // Row blocks: balanced over L, at most 64 rows, and -- if a finer split gets there -- small enough for FOUR
+    // workgroups per CU (<= 40 KiB of LDS): measured at L = 197, hd = 64: 4 blocks of 50 rows (45 KiB, 3 / CU) 100 us,
+    // 5 blocks of 40 (38 KiB, 4 / CU) 84 us, 6 blocks 92 us (more halo rows per owned row).
+    auto geometry = [&](int nb, int& rbv, int& kr, int& nt) {
+      rbv = (L + nb - 1) / nb;
+      const int nbe = (L + rbv - 1) / rbv;
+      kr = (rbv + 4 * h) + 2 * (2 * h + 1);
+      // query tiles: the main rows + the wrap tiles of keys 0 / L-1 (both only when one block holds the whole sequence)
+      nt = (rbv + 2 * h + 15) / 16 + (nbe >= 2 ? 1 : 2);
+      return (size_t)2 * kr * rs + (size_t)2 * 16 * nt * rs + (size_t)16 * nt * 8;
+    };
+    const int nb0 = (L + 63) / 64;
+    int nblk = nb0, rbv, krows, ntl;
+    for (int nb = nb0; nb <= 2 * nb0 && nb <= L; ++nb) {
+      if (geometry(nb, rbv, krows, ntl) <= 40 * 1024) { nblk = nb; break; }
+    }
+    { const char* e = getenv("FAVIT_MHLA_BLOCKS"); if (e && atoi(e) > 0 && (L + atoi(e) - 1) / atoi(e) <= 64) nblk = atoi(e); }
+    AttnArgs a2 = a;
+    (void)geometry(nblk, rbv, krows, ntl);
+    a2.rb = rbv;
+    nblk = (L + a2.rb - 1) / a2.rb;
+    const size_t lds = (size_t)2 * krows * rs + (size_t)2 * 16 * ntl * rs + (size_t)16 * ntl * 8;
+    if (lds <= 160 * 1024 && krows <= 108 && 16 * ntl <= 112) {
+      dim3 grid(nblk, H, B);
+      const bool plain = (mask == nullptr) && (a2.thresh == 0);
+#define FAVIT_MFMA2(HDV, PL)                                                                                  \
+  do {                                                                                                        \
+    if (lds > 65536) favit_ensure_dyn_lds(reinterpret_cast<const void*>(mhla_bwd_mfma2_kernel<HDV, PL>), (int)lds); \
+    hipLaunchKernelGGL((mhla_bwd_mfma2_kernel<HDV, PL>), grid, dim3(256), lds, st, a2);                       \
+  } while (0)
+      if (hd == 32) { if (plain) FAVIT_MFMA2(32, true); else FAVIT_MFMA2(32, false); }
+      else if (hd == 64) { if (plain) FAVIT_MFMA2(64, true); else FAVIT_MFMA2(64, false); }
+      else { if (plain) FAVIT_MFMA2(128, true); else FAVIT_MFMA2(128, false); }
+#undef FAVIT_MFMA2
       FAVIT_CHECK_LAUNCH();
       return FAVIT_OK;
     }
   }
+  // The table formulation of the MFMA backward (opt-in: FAVIT_MHLA_BWD_MFMA=1 or FAVIT_MHLA_BWD_TABLES=1): measured
+  // 189 us at the bench shape against 131 us for the 8-lanes-per-row kernel (72 KiB of LDS allow only two
+  // workgroups per CU and every phase is latency-bound).
   if (dtype == FAVIT_F32) return W <= 7 ? dispatch_dpl<float, 7>(bwd, a, st) : dispatch_dpl<float, 15>(bwd, a, st);
   if (dtype == FAVIT_BF16) return W <= 7 ? dispatch_dpl<bf16_t, 7>(bwd, a, st) : dispatch_dpl<bf16_t, 15>(bwd, a, st);
   return FAVIT_ERR_INVALID;

@@ -216,8 +216,7 @@ __global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
     }
     float wA[8], wB[8];                                // B operands of the transposed products: dS and Pd
     if (MODE == 0) {
-      bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      bm = quad16_max(bm);
       const float m_new = fmaxf(m_run, bm);
       const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;       // a fully masked prefix: no NaN in flight
       const float alpha = __expf(m_run - m_safe);
@@ -256,8 +255,7 @@ __global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
 
   // ---- store: the lane holds, for owner row `on`, columns d0 + 16 dt + 4g .. + 3 ----
   if (MODE == 0) {
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
+    l_run = quad16_sum(l_run);
     const float inv = 1.0f / l_run;                    // a fully masked row: 0 * inf = NaN, as torch's softmax
     if (on < Lo) {
       T* orow = reinterpret_cast<T*>(a.out0) + b * a.vo0.sb + h * a.vo0.sh + (long)on * a.vo0.ld;

@@ -194,15 +194,16 @@ def test_embed_prologue(K, B, N, D, dtype):
                                            (17, 5, 32, True), (65, 7, 64, False), (197, 7, 64, False),
                                            (197, 15, 16, False), (33, 9, 128, False), (64, 7, 64, False),
                                            (100, 3, 64, True)])
-@pytest.mark.parametrize("bwd_mfma", [False, True])
-def test_mhla_core_fwd_bwd_vs_window_gather(K, dtype, L, W, hd, masked, bwd_mfma, monkeypatch):
+@pytest.mark.parametrize("bwd_kernel", ["default", "tables", "valu"])
+def test_mhla_core_fwd_bwd_vs_window_gather(K, dtype, L, W, hd, masked, bwd_kernel, monkeypatch):
     """The attention core against a direct restatement of the reference's gather-based windows
-    (duplicated pad indices take part in the softmax, models/mhla.py:117-154)."""
+    (duplicated pad indices take part in the softmax, models/mhla.py:117-154).  bf16, hd >= 32 has three
+    backward kernels: the default two-owner-pass MFMA kernel, the table formulation and the 8-lanes-per-row one."""
     from oracle import favit_oracle as O
-    if bwd_mfma:
+    if bwd_kernel != "default":
         if dtype != torch.bfloat16 or hd < 32:
-            pytest.skip("the MFMA backward exists for bf16, hd >= 32")
-        monkeypatch.setenv("FAVIT_MHLA_BWD_MFMA", "1")      # read by the library at call time
+            pytest.skip("kernel selection only exists for bf16, hd >= 32")
+        monkeypatch.setenv("FAVIT_MHLA_BWD_TABLES" if bwd_kernel == "tables" else "FAVIT_MHLA_VALU", "1")   # read per call
     B, H = 2, 3
     D = H * hd
     g = torch.Generator(device=DEV).manual_seed(L * 31 + W)
