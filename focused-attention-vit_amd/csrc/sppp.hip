@@ -8,18 +8,55 @@
 namespace {
 
 // ---- dominant label per patch: max count, ties -> smallest label (sppp.py:117-120) ----
+// One wave per patch.  The labels of a patch are few (a superpixel map has 1-4 distinct labels per 16x16 patch), so
+// the wave peels them off one at a time: take the label of the first lane that still has an uncounted pixel, count
+// its occurrences with ballots, mark them counted.  Cost ~ (distinct labels) x (pixels / 64) wave steps instead of
+// the pixels^2 / 64 comparisons of a per-pixel count (188 -> ~20 us at 128 images of 224 x 224, P = 16).
 __global__ __launch_bounds__(64) void dominant_label_kernel(const int64_t* __restrict__ seg, int64_t* __restrict__ dom,
                                                             int HW, int P) {
-  extern __shared__ int64_t lab[];       // P*P labels of this patch
+  extern __shared__ int64_t lab[];       // P*P labels of this patch (patches with more than 64 x 16 pixels)
   const int g = HW / P, n = P * P;
   const int patch = blockIdx.x, b = blockIdx.y;
   const int ph = patch / g, pw = patch % g;
+  const int lane = threadIdx.x;
   const int64_t* img = seg + (long)b * HW * HW;
-  for (int e = threadIdx.x; e < n; e += 64) lab[e] = img[(long)(ph * P + e / P) * HW + pw * P + e % P];
+  constexpr int PER = 16;                // pixels per lane held in registers (n <= 1024); larger patches use the LDS copy
+  const bool in_regs = n <= 64 * PER;
+  int64_t v[PER];
+  unsigned todo = 0;                     // bit k: v[k] holds an uncounted pixel
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int e = lane + 64 * k;
+      if (e < n) { v[k] = img[(long)(ph * P + e / P) * HW + pw * P + e % P]; todo |= 1u << k; }
+      else v[k] = 0;
+    }
+    int best_c = -1;
+    int64_t best_l = 0;
+    while (__ballot(todo != 0)) {
+      const int leader = __ffsll((long long)__ballot(todo != 0)) - 1;
+      const int k0 = __ffs((int)todo) - 1;                              // meaningful on the leader lane only
+      int64_t mine = 0;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) if (k == k0) mine = v[k];
+      const int64_t l = __shfl(mine, leader, 64);
+      int c = 0;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const bool hit = ((todo >> k) & 1u) && v[k] == l;
+        c += __popcll(__ballot(hit));
+        if (hit) todo &= ~(1u << k);
+      }
+      if (c > best_c || (c == best_c && l < best_l)) { best_c = c; best_l = l; }
+    }
+    if (lane == 0) dom[(long)b * g * g + patch] = best_l;
+    return;
+  }
+  for (int e = lane; e < n; e += 64) lab[e] = img[(long)(ph * P + e / P) * HW + pw * P + e % P];
   __syncthreads();
   int best_c = -1;
   int64_t best_l = 0;
-  for (int e = threadIdx.x; e < n; e += 64) {
+  for (int e = lane; e < n; e += 64) {
     const int64_t l = lab[e];
     int c = 0;
     for (int f = 0; f < n; ++f) c += (lab[f] == l);
@@ -30,7 +67,7 @@ __global__ __launch_bounds__(64) void dominant_label_kernel(const int64_t* __res
     const int64_t ol = __shfl_xor(best_l, o, 64);
     if (oc > best_c || (oc == best_c && ol < best_l)) { best_c = oc; best_l = ol; }
   }
-  if (threadIdx.x == 0) dom[(long)b * g * g + patch] = best_l;
+  if (lane == 0) dom[(long)b * g * g + patch] = best_l;
 }
 
 // ---- token rank = first-appearance order of dominant labels (sppp.py:124-126) ----
@@ -195,24 +232,43 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 }
 
 // ---- centroids per LABEL (sppp_mhla.py:226-262): exact integer coordinate sums ----
-__global__ __launch_bounds__(256) void centroid_kernel(const int64_t* __restrict__ seg, float* __restrict__ cent,
-                                                       int HW, int S) {
+// Pixels that neighbour each other mostly share a label: a wave reduces (count, sum x, sum y) over the lanes that
+// hold the same label with shuffles and issues ONE set of LDS atomics per distinct label per 64 pixels, instead of
+// three 64-bit LDS atomics per pixel (119 -> ~15 us at 128 images of 224 x 224).  Integer sums: order-independent.
+__global__ __launch_bounds__(1024) void centroid_kernel(const int64_t* __restrict__ seg, float* __restrict__ cent,
+                                                        int HW, int S) {
   extern __shared__ unsigned long long acc[];     // [S][3]: count, sum x, sum y
-  const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < 3 * S; i += 256) acc[i] = 0ull;
+  const int b = blockIdx.x, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 3 * S; i += 1024) acc[i] = 0ull;
   __syncthreads();
   const int64_t* img = seg + (long)b * HW * HW;
   const long n = (long)HW * HW;
-  for (long i = threadIdx.x; i < n; i += 256) {
-    const int64_t l = img[i];
-    if (l >= 0 && l < S) {
-      atomicAdd(&acc[3 * l], 1ull);
-      atomicAdd(&acc[3 * l + 1], (unsigned long long)(i % HW));
-      atomicAdd(&acc[3 * l + 2], (unsigned long long)(i / HW));
+  const long trips = (n + 1023) / 1024;
+  for (long t = 0; t < trips; ++t) {
+    const long i = t * 1024 + threadIdx.x;
+    int64_t l = -1;
+    if (i < n) l = img[i];
+    bool live = l >= 0 && l < S;
+    const unsigned x = live ? (unsigned)(i % HW) : 0u, y = live ? (unsigned)(i / HW) : 0u;
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int64_t ll = __shfl(l, leader, 64);
+      const bool in = live && l == ll;
+      const unsigned long long grp = __ballot(in);
+      unsigned sx = in ? x : 0u, sy = in ? y : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); }
+      if (lane == leader) {
+        atomicAdd(&acc[3 * ll], (unsigned long long)__popcll(grp));
+        atomicAdd(&acc[3 * ll + 1], (unsigned long long)sx);
+        atomicAdd(&acc[3 * ll + 2], (unsigned long long)sy);
+      }
+      todo &= ~grp;
     }
   }
   __syncthreads();
-  for (int s = threadIdx.x; s < S; s += 256) {
+  for (int s = threadIdx.x; s < S; s += 1024) {
     const unsigned long long c = acc[3 * s];
     float cx = 0.5f, cy = 0.5f;
     if (c > 0) {
@@ -295,7 +351,7 @@ extern "C" int favit_sppp_pool_bwd(const float* dout, const float* emb, const in
 extern "C" int favit_sppp_centroids(const int64_t* seg, float* cent, int32_t B, int32_t HW, int32_t S, void* stream) {
   if (!seg || !cent || B <= 0 || HW <= 0 || S <= 0) return FAVIT_ERR_INVALID;
   if (S > 2048) return FAVIT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(centroid_kernel, dim3(B), dim3(256), sizeof(unsigned long long) * 3 * S, as_stream(stream), seg, cent, HW, S);
+  hipLaunchKernelGGL(centroid_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * 3 * S, as_stream(stream), seg, cent, HW, S);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }

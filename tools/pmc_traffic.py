@@ -3,8 +3,21 @@
 into per-kernel HBM traffic per launch.  gfx950: FETCH_SIZE counts wide coalesced reads at half
 their size (MI355X_MICROARCH.md), so bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB.
 
+The JSON is stamped with the fingerprint of csrc/ (the same one bench.py computes): bench.py only reports the
+traffic figure as current while the kernel sources are the ones the passes were taken on.
+
 usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <out.txt>"""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha16():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "focused-attention-vit_amd", "csrc", "*"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 FAMILY = {  # bench.py GEMM family key -> substring(s) identifying the kernel instantiation
     "bf16_KM_obf16": ("gemm_bf16_p4_kernelILb1ELb0EDF16b", "gemm_bf16_p4_kernel<true, false, __bf16>"),
@@ -44,9 +57,14 @@ def main():
                 fam[key] = {"kernel": k[:90], "hbm_bytes_per_launch": int((2 * f + w) * 1024), "fetch_kib": f,
                             "write_kib": w, "launches_sampled": n}
                 break
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        head = None
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) -- python bench.py "
                          "--steps 2 --warmup 1; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE halves "
-                         "wide coalesced reads, MI355X_MICROARCH.md)", "families": fam}, open(oj, "w"), indent=1)
+                         "wide coalesced reads, MI355X_MICROARCH.md)", "config": "cfg2", "dtype": "bf16",
+               "csrc_sha16": csrc_sha16(), "git_head_when_folded": head, "families": fam}, open(oj, "w"), indent=1)
     with open(ot, "w") as o:
         o.write("HBM traffic per launch from rocprofv3 PMC (separate passes: --pmc FETCH_SIZE / --pmc WRITE_SIZE) over "
                 "`python bench.py --steps 2 --warmup 1`\nunits: counter value is KiB; per MI355X_MICROARCH.md FETCH_SIZE "
