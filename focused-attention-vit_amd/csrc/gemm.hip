@@ -2006,15 +2006,22 @@ long grouped_slab_floats(const favit_gemm_t* gs, int count) {
   return (tot + 63) / 64 * 64;
 }
 
-long grouped_nsplit(long total_tiles) {
-  // splits = 8*s: one group of s splits per XCD; pick s that fills the 64 slots of an XCD best
+// splits = 8*s: one group of s splits per XCD; the s <= 4 that fills the 64 workgroup slots of an XCD best among
+// those that leave every split at least one K-step (short token counts: fewer splits, not a refusal).
+// Returns 0 if even 8 splits do not fit.
+long grouped_nsplit(long total_tiles, long K, long* kps_out) {
   double best = -1.0;
-  long best_s = 1;
+  long best_s = 0, best_kps = 0;
   for (long s = 1; s <= 4; ++s) {
+    const long nsplit = 8 * s;
+    long kps = (K + nsplit - 1) / nsplit;
+    kps = ((kps + P4_BK - 1) / P4_BK) * P4_BK;
+    if ((nsplit - 1) * kps >= K) continue;            // the last split would be empty
     const long w = total_tiles * s;
     const double util = (double)w / (double)(((w + 63) / 64) * 64);
-    if (util > best + 0.02) { best = util; best_s = s; }
+    if (util > best + 0.02) { best = util; best_s = s; best_kps = kps; }
   }
+  if (kps_out) *kps_out = best_kps;
   return 8 * best_s;
 }
 
@@ -2067,10 +2074,9 @@ int grouped_tn_impl(const favit_gemm_t* gs, int32_t count, float* ws, int64_t ws
   }
   gp.tile_off[count] = off;
   gp.total_tiles = off;
-  const long nsplit = grouped_nsplit(off);
-  long kps = (K + nsplit - 1) / nsplit;
-  kps = ((kps + P4_BK - 1) / P4_BK) * P4_BK;
-  if ((nsplit - 1) * kps >= K) return FAVIT_ERR_UNSUPPORTED;       // too few tokens to split 8 ways
+  long kps = 0;
+  const long nsplit = grouped_nsplit(off, K, &kps);
+  if (nsplit == 0) return FAVIT_ERR_UNSUPPORTED;                    // too few tokens to split 8 ways
   gp.nsplit = (int)nsplit;
   for (int i = 0; i < count; ++i) gp.p[i].k_per_split = kps;
 
@@ -2134,7 +2140,7 @@ extern "C" int64_t favit_gemm_grouped_tn_workspace(const favit_gemm_t* gs, int32
   if (!gs || count <= 0 || count > GROUP_MAX) return 0;
   long tiles = 0;
   for (int i = 0; i < count; ++i) tiles += ((gs[i].M + P4_BM - 1) / P4_BM) * ((gs[i].N + BN - 1) / BN);
-  return (int64_t)(grouped_nsplit(tiles) * grouped_slab_floats(gs, count) * 4);
+  return (int64_t)(grouped_nsplit(tiles, gs[0].K, nullptr) * grouped_slab_floats(gs, count) * 4);
 }
 
 extern "C" int favit_gemm_grouped_tn_ws(const favit_gemm_t* gs, int32_t count, void* workspace, int64_t workspace_bytes,

@@ -32,7 +32,7 @@ def _rand(shape, dtype, gen, scale=1.0):
     return (torch.randn(shape, generator=gen, device=DEV, dtype=torch.float32) * scale).to(dtype)
 
 
-def _block_problems(T, gen, accumulate):
+def _block_problems(T, gen, accumulate, D=D):
     """The four dW = dY^T X problems of one transformer block (fc2, fc1, proj, folded qkv)."""
     shapes = [(D, 4 * D), (4 * D, D), (D, D), (3 * D, D)]          # (N, K) of dW[N, K]
     probs, refs = [], []
@@ -87,10 +87,22 @@ def test_gemm_grouped_tn_slab_reduction_is_deterministic(K):
             assert torch.equal(w0, w1) and torch.equal(b0, b1)
 
 
+def test_gemm_grouped_tn_short_token_counts(K):
+    """ViT-Tiny at 64 images x 65 tokens (BASELINE.json configs[0]): 20 tiles would like 24 K-splits, 4,160 tokens
+    only feed 16 -- the launch takes the best feasible split count instead of declining."""
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    probs, refs = _block_problems(64 * 65, gen, True, D=192)
+    assert K.gemm_grouped_tn(probs)
+    for (dy, x, dw, db, _), (ref_w, ref_b) in zip(probs, refs):
+        assert rel_l2(dw, ref_w) < 2e-5 and rel_l2(db, ref_b) < 2e-5
+
+
 def test_gemm_grouped_tn_declines_what_it_cannot_group(K):
     gen = torch.Generator(device=DEV).manual_seed(3)
     T = 197 * 2                                  # not a multiple of 32: callers fall back to single launches
     probs, _ = _block_problems(T, gen, False)
+    assert K.gemm_grouped_tn(probs) is False
+    probs, _ = _block_problems(224, gen, False)  # 8 splits of >= 32 tokens do not fit
     assert K.gemm_grouped_tn(probs) is False
 
 
