@@ -1899,12 +1899,12 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
     if (g->out_dtype == FAVIT_BF16) return launch_p7(gemm_bf16_p7_kernel<bf16_t>, k7, grid7, st);
     return launch_p7(gemm_bf16_p7_kernel<float>, k7, grid7, st);
   }
-  // ping-pong kernel: single-pass problems with a k-major A and a LONG reduction (K >= 2048: the ViT-Base
-  // input-gradient GEMMs, large squares) that the 256x256 kernel cannot take (mn-major B, or N % 256 != 0).
-  // Measured (tools/gemm_bench.py, tools/pp_probe.py): 8192^3 1053-1081 TF against 962 TF for p4 on the same
-  // device; a tie at K = 1536 and a loss at K = 384, where one workgroup per CU leaves prologue and epilogue
-  // uncovered -- so the training step's K <= 1536 shapes stay on p4.  FAVIT_GEMM_PP=1 forces it (tests).
-  const bool pp_shape = (g->K >= 2048 && t4 >= 256) || getenv("FAVIT_GEMM_PP") != nullptr;   // read per call: tests toggle it
+  // ping-pong kernel: single-pass problems with a k-major A and a VERY long reduction (K >= 4096) that the 256x256
+  // kernel cannot take (mn-major B, or N % 256 != 0).  Measured (tools/gemm_bench.py, tools/pp_probe.py): 8192^3
+  // 1053-1081 TF against 962 TF for p4 on the same device; but 203 vs 175 us and 153 vs 134 us on the ViT-Base
+  // input-gradient GEMMs (K = 3072 / 2304, 870 tiles: one workgroup per CU loses to p4's two), a tie at K = 1536 and
+  // a loss at K = 384 -- so every GEMM of the training configurations stays on p4.  FAVIT_GEMM_PP=1 forces it (tests).
+  const bool pp_shape = (g->K >= 4096 && t4 >= 256) || getenv("FAVIT_GEMM_PP") != nullptr;   // read per call: tests toggle it
   if (glds_ok && !force128 && !knobs().no_pp && pp_shape && splits == 1 && !atomic && batch == 1 && g->a_kmajor &&
       !g->a_rowsum && g->M >= 256 && (g->K % BK16) == 0 && g->K >= 2 * BK16) {
     dim3 gridp((unsigned)t4, 1u, 1u);

@@ -102,7 +102,10 @@ class FusedAdamW:
     def zero_grad(self):
         for g in self.groups:
             g["flat"].zero_grad()
-            if g["lp"] is not None:          # pick up in-place parameter edits made between steps
+            # The bf16 mirror is rewritten by the AdamW kernel and validated per parameter at every use
+            # (functional._LPMirror), so eager steps need no refresh here.  A captured step cannot run that host-side
+            # check at replay time: the capture records one full re-cast per step instead.
+            if g["lp"] is not None and torch.cuda.is_current_stream_capturing():
                 K.cast(g["flat"].flat_p, torch.bfloat16, out=g["lp"])
                 g["mirror"].mark_synced()
 

@@ -542,12 +542,12 @@ def test_gemm_256x256_tile_kernel(K, bk, out_dtype, epi):
 
 
 @pytest.mark.parametrize("bk", [True, False])
-@pytest.mark.parametrize("M,N,Kd,forced", [(8192 + 40, 1024 + 128, 2048, False), (2048 + 40, 384, 512, True),
+@pytest.mark.parametrize("M,N,Kd,forced", [(8192 + 40, 1024 + 128, 4096, False), (2048 + 40, 384, 512, True),
                                            (1024, 200, 128, True), (300, 128, 1536, True)])
 @pytest.mark.parametrize("out_dtype,epi", [(torch.bfloat16, "gelu"), (torch.bfloat16, "dgelu"), (torch.float32, "res")])
 def test_gemm_ping_pong_kernel(K, bk, M, N, Kd, forced, out_dtype, epi, monkeypatch):
     """The 12-wave ping-pong kernel (two MFMA halves one barrier apart + four loader waves): taken by itself for
-    K >= 2048 problems the 256x256 kernel cannot serve, forced (FAVIT_GEMM_PP, read per call) on small / ragged /
+    K >= 4096 problems the 256x256 kernel cannot serve, forced (FAVIT_GEMM_PP, read per call) on small / ragged /
     short-K shapes (2 .. 24 stages, ragged M and N, both B layouts, fused epilogues)."""
     if forced:
         monkeypatch.setenv("FAVIT_GEMM_PP", "1")
