@@ -180,6 +180,9 @@ def main():
     ap.add_argument("--no-gemm-trace", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="cfg1 / cfg3: eager launches instead of the replayed HIP graph")
     ap.add_argument("--side-stream", action="store_true", help="run weight-gradient GEMMs on a second HIP stream")
+    ap.add_argument("--host-input", action="store_true",
+                    help="also measure the PCIe-inclusive rate: uint8 HWC batches in pinned HOST memory -> async copy + "
+                         "device transform (data.DeviceLoader) -> step; reported as `pcie_inclusive`, never as `value`")
     args = ap.parse_args()
     c = CONFIGS[args.config]
 
@@ -255,6 +258,29 @@ def main():
     dt = float(t.item())
     loss_val = float(loss.item())
 
+    # PCIe-inclusive rate (informational): every step consumes a fresh uint8 batch from pinned host memory
+    pcie = None
+    if args.host_input and not graphed:
+        D_ = pkg.data
+        tf = D_.DeviceTransform("resize", c["img"], (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+        rs = np.random.RandomState(7 + rank)
+        host = [(torch.from_numpy(rs.randint(0, 256, size=(B, c["img"], c["img"], 3), dtype=np.uint8)).pin_memory(),
+                 torch.from_numpy(rs.randint(0, c["classes"], size=B).astype(np.int64)).pin_memory()) for _ in range(4)]
+        n_it = max(4, args.steps)
+        batches = [host[i % 4] for i in range(n_it + 2)]
+        it = iter(D_.DeviceLoader(batches, tf, device=dev))
+        for _ in range(2):
+            xb, yb = next(it)
+            pkg.train.train_step(model, xb, yb, opt)
+        sync()
+        tp0 = time.perf_counter()
+        for xb, yb in it:
+            pkg.train.train_step(model, xb, yb, opt)
+        sync()
+        tp = time.perf_counter() - tp0
+        pcie = {"images_per_sec": round(world * B * n_it / tp, 2), "ms_per_step": round(1e3 * tp / n_it, 3),
+                "input": f"uint8 HWC {c['img']}x{c['img']}x3 from pinned host memory, async copy stream + device transform"}
+
     # per-launch GEMM timing: two extra EAGER steps after the timed region (events cannot be captured in a graph).
     # Every rank runs them (the all-reduce inside opt.step() is collective); only rank 0 records events.
     trace, traced_steps, opt_ms = None, 0, None
@@ -293,6 +319,8 @@ def main():
         }
         if opt_ms is not None:
             out["optimizer_and_allreduce_wait_ms"] = round(opt_ms, 3)
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
         if trace:
             fam = {}
             for e0, e1, fl, key, shp in trace:

@@ -150,17 +150,25 @@ class DeviceLoader:
     def _stage(self, slot: int, imgs, labels):
         imgs = torch.as_tensor(np.asarray(imgs)) if not torch.is_tensor(imgs) else imgs
         labels = torch.as_tensor(np.asarray(labels), dtype=torch.int64) if not torch.is_tensor(labels) else labels.to(torch.int64)
-        buf = self._pin[slot]
-        if buf is None or buf[0].shape != imgs.shape or buf[1].shape != labels.shape:
-            buf = (torch.empty(imgs.shape, dtype=torch.uint8).pin_memory(), torch.empty(labels.shape, dtype=torch.int64).pin_memory())
-            self._pin[slot] = buf
-        buf[0].copy_(imgs)
-        buf[1].copy_(labels)
+        if imgs.is_pinned() and labels.is_pinned():
+            src = (imgs, labels)                          # the producer already wrote into page-locked memory: no staging copy
+        else:
+            buf = self._pin[slot]
+            if buf is None or buf[0].shape != imgs.shape or buf[1].shape != labels.shape:
+                buf = [torch.empty(imgs.shape, dtype=torch.uint8).pin_memory(), torch.empty(labels.shape, dtype=torch.int64).pin_memory(), None]
+                self._pin[slot] = buf
+            if buf[2] is not None:
+                buf[2].synchronize()                      # the previous copy out of this staging buffer has finished
+            buf[0].copy_(imgs)
+            buf[1].copy_(labels)
+            src = (buf[0], buf[1])
         with torch.cuda.stream(self.copy_stream):
-            d_img = buf[0].to(self.dev, non_blocking=True)
-            d_lab = buf[1].to(self.dev, non_blocking=True)
+            d_img = src[0].to(self.dev, non_blocking=True)
+            d_lab = src[1].to(self.dev, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
+        if src[0] is not imgs:
+            self._pin[slot][2] = ev
         return d_img, d_lab, ev
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
