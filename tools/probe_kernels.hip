@@ -107,3 +107,71 @@ extern "C" int probe_dma(const void* A, const void* W, long lda, long ldw, long 
   else return -1;
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---- do two workgroups on one CU share operand lines through the CU's L1? ----
+// 512 persistent workgroups (two per CU).  Each reads its placement (XCC / SE / SH / CU ids), takes slot 0 or 1 of its CU
+// from a table, and streams the operand traffic of `ntile` 256x128x(32*ksteps) GEMM tiles (16 KiB of A + 8 KiB of B per
+// k-step, three stages, like the p4 kernel).  mode 0: the two workgroups of a CU stream DIFFERENT A tiles;
+// mode 1: the SAME A tile (adjacent N tiles of one M panel).  census[key] counts workgroups per CU.
+__global__ __launch_bounds__(512) void dma_share_probe(const char* A, const char* W, long a_tile_bytes, long w_tile_bytes,
+                                                       int ntile, int ksteps, int mode, unsigned* census, unsigned* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned s_key, s_slot;
+  constexpr int STAGE = 384 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));        // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));      // HW_REG_XCC_ID
+    const unsigned key = ((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF);         // cu_id[11:8] sh_id[12] se_id[15:13]
+    s_key = key;
+    s_slot = atomicAdd(census + key, 1u);
+  }
+  __syncthreads();
+  const unsigned key = s_key, slot = s_slot;
+  unsigned acc = 0;
+  for (int t = 0; t < ntile; ++t) {
+    long a_idx = (mode & 1) ? ((long)key * ntile + t) : (((long)key * 2 + (slot & 1)) * ntile + t);
+    if (mode & 2) a_idx = (mode & 1) ? ((long)(key & 0xFF) + t) % 16 : ((long)(key & 0xFF) * 2 + (slot & 1) + t) % 16;   // L2-resident set
+    const long w_idx = ((long)key * 2 + (slot & 1)) % 64;
+    const char* a0 = A + a_idx * a_tile_bytes;
+    const char* w0 = W + w_idx * w_tile_bytes;
+    const char* src[3];
+    int dst[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int q = wave * 3 + j, row = q * 16 + lane / 4, c = lane % 4;       // 24 pieces of 16 rows x 64 B
+      src[j] = row < 256 ? a0 + (long)row * (ksteps * 64) + c * 16 : w0 + (long)(row - 256) * (ksteps * 64) + c * 16;
+      dst[j] = q * 1024;
+    }
+    auto issue = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        __builtin_amdgcn_global_load_lds((gptr_t)src[j], (lptr_t)(smem + buf * STAGE + dst[j]), 16, 0, 0);
+        src[j] += 64;
+      }
+    };
+    issue(0);
+    if (ksteps > 1) issue(1);
+    int cur = 0;
+    for (int kt = 0; kt < ksteps; ++kt) {
+      if (kt + 1 < ksteps) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < ksteps) issue(cur >= 1 ? cur - 1 : 2);
+      acc += *reinterpret_cast<const unsigned*>(smem + cur * STAGE + tid * 16);
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+    __syncthreads();
+  }
+  if (acc == 0x13572468u) sink[0] = acc;
+}
+
+extern "C" int probe_dma_share(const void* A, const void* W, long a_tile_bytes, long w_tile_bytes, int ntile, int ksteps,
+                               int mode, void* census, void* stream) {
+  static unsigned* sink = nullptr;
+  if (!sink) hipMalloc(&sink, 64);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(dma_share_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24576);
+  hipLaunchKernelGGL(dma_share_probe, dim3(512), dim3(512), 3 * 24576, (hipStream_t)stream, (const char*)A, (const char*)W,
+                     a_tile_bytes, w_tile_bytes, ntile, ksteps, mode, (unsigned*)census, sink);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
