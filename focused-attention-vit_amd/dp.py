@@ -97,7 +97,7 @@ class GradSync:
         for parameters autograd never sees a gradient for."""
         i = self._index.get(id(p))
         if i is not None and self.world > 1:
-            self._make_hook(i)(p)
+            self._event(i, p, True)
 
     def no_sync(self):
         """Context manager for gradient accumulation: backward passes inside it only accumulate into the
@@ -116,26 +116,38 @@ class GradSync:
 
     def _make_hook(self, i):
         def hook(_p):
-            if self.defer:             # graph capture / replay / no_sync(): finish() launches every bucket afterwards
-                return
-            b = self._bucket_of[i]
-            if self._launched[b]:
-                # A gradient arrived for a bucket whose all-reduce is already in flight: a second backward
-                # before step() (gradient accumulation without no_sync()) or a parameter used twice in one
-                # forward.  The reduced values would miss this contribution and differ across ranks.
-                raise RuntimeError(
-                    "GradSync: gradient of a parameter accumulated after its bucket's all-reduce was launched; "
-                    "wrap all but the last backward of a step in GradSync.no_sync() (FusedAdamW.no_sync())")
-            self._seen[b].add(i)
-            if len(self._seen[b]) == self._pending[b]:
-                self._launch(b)
+            self._event(i, _p, False)
         return hook
+
+    def _event(self, i, p, direct):
+        """Parameter i has (another contribution to) its gradient in the flat buffer.  direct: reported by a kernel
+        launch sequence that wrote the gradient itself; otherwise autograd's post-accumulate hook."""
+        if self.defer:                 # graph capture / replay / no_sync(): finish() launches every bucket afterwards
+            return
+        b = self._bucket_of[i]
+        prev = self._seen[b].get(i)
+        if prev is not None:
+            if prev and not direct:
+                # autograd runs the AccumulateGrad node (and this hook) of a parameter even when the custom Function
+                # returned None for it -- i.e. right after the kernels reported the same gradient directly
+                return
+            # A real second contribution: a second backward before step() (gradient accumulation without no_sync())
+            # or a parameter used twice in one forward.  If the bucket is already on the wire the reduced values
+            # would miss it and differ across ranks.
+            if self._launched[b]:
+                raise RuntimeError(
+                    f"GradSync: gradient of parameter #{i} {tuple(p.shape)} accumulated after its bucket's all-reduce "
+                    "was launched; wrap all but the last backward of a step in GradSync.no_sync() (FusedAdamW.no_sync())")
+            return
+        self._seen[b][i] = direct
+        if len(self._seen[b]) == self._pending[b]:
+            self._launch(b)
 
     def reset(self):
         for b, (_, _, idxs) in enumerate(self.buckets):
             self._pending[b] = len(idxs)          # distinct parameters whose gradient must have arrived
             self._launched[b] = False
-        self._seen = [set() for _ in self.buckets]
+        self._seen = [dict() for _ in self.buckets]      # parameter index -> reported directly by the kernels?
         self._handles = []
 
     def _launch(self, b):

@@ -1,0 +1,81 @@
+"""The overlapped data-parallel path through the REAL kernels: two ranks (gloo backend, both on the
+one GPU of the test box -- RCCL needs one GPU per rank) run forward / backward of ViT-MHLA on half a batch each with
+direct gradient accumulation into the flat buffers, kernel-side grad_ready calls, bucket all-reduces launched during
+backward and FusedAdamW's finish(average=False) / grad_scale = 1/world.  The averaged gradients must equal the
+single-process gradients of the whole batch, and after two optimizer steps both ranks must hold the same weights.
+(autograd also fires the post-accumulate hook of a parameter whose gradient the kernels wrote directly; GradSync must
+not count that as a second contribution -- the regression this test pins.)"""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _model(pkg):
+    torch.manual_seed(3)
+    return pkg.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2,
+                                                     num_heads=4, window_size=7, use_mhla=True).cuda().train()
+
+
+def _batch():
+    g = torch.Generator().manual_seed(5)
+    return torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 10, (8,), generator=g)
+
+
+def _worker(rank, world, port, out, mode):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("focused-attention-vit_amd")
+    pkg.set_compute_dtype(mode)
+    m = _model(pkg)
+    opt = pkg.train.FusedAdamW(pkg.train.param_groups(m, lr=1e-2), lr=1e-2, weight_decay=0.0, bucket_mb=0.05)
+    assert all(g["sync"] is not None and len(g["sync"].buckets) >= 1 for g in opt.groups)
+    x, y = _batch()
+    lo = rank * 4
+    xs, ys = x[lo:lo + 4].cuda(), y[lo:lo + 4].cuda()
+    opt.zero_grad()
+    pkg.train.cross_entropy(m(xs), ys).backward()
+    launched = [all(g["sync"]._launched) for g in opt.groups]           # every bucket went out DURING backward
+    for g in opt.groups:
+        g["sync"].finish(average=False)
+    grads = {k: (p.grad / world).detach().cpu().clone() for k, p in m.named_parameters()}
+    # two real optimizer steps: the ranks must stay in lock-step
+    for _ in range(2):
+        pkg.train.train_step(m, xs, ys, opt)
+    torch.cuda.synchronize()
+    w = torch.cat([p.detach().flatten().cpu() for p in m.parameters()])
+    torch.save({"grads": grads, "w": w, "launched": launched}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+def test_dp_two_ranks_through_the_kernels(favit, tmp_path, mode, tol):
+    out = str(tmp_path / "dp")
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out, mode), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0", weights_only=True), torch.load(out + ".1", weights_only=True)
+    assert all(r0["launched"]) and all(r1["launched"])
+    assert torch.equal(r0["w"], r1["w"]), "the two ranks diverged"
+    favit.set_compute_dtype(mode)
+    try:
+        m = _model(favit)
+        x, y = _batch()
+        favit.train.cross_entropy(m(x.cuda()), y.cuda()).backward()
+        for k, p in m.named_parameters():
+            ref = p.grad.detach().cpu()
+            for r in (r0, r1):
+                err = (r["grads"][k] - ref).norm() / max(ref.norm().item(), 1e-12)
+                assert err < tol, (k, float(err))
+    finally:
+        favit.set_compute_dtype("fp32")
