@@ -546,6 +546,31 @@ __device__ __forceinline__ int slot_key(int slot, int t0, int h, int L) {
   return min(max(j, 0), L - 1);
 }
 
+
+// Output tiles of the transposed products (O^T, dQ^T, dK^T, dV^T) in a column order that lets a lane store 32
+// contiguous bytes: tile t = 4*half + sub of the MFMA sequence covers the columns d = 64*half + 16*(m/4) + 4*sub + m%4
+// (m = MFMA row), i.e. lane group g ends up with the 16 consecutive columns 64*half + 16g .. +15 over sub = 0..3.
+// The permutation costs nothing: a ds_read_b64_tr_b16 lane supplies its own column address.
+__device__ __forceinline__ int tr_col(int t, int p4) { return 64 * (t >> 2) + 16 * p4 + 4 * (t & 3); }
+
+template <int HD>
+__device__ __forceinline__ void store_rows16(bf16_t* row, const f32x4 (&o)[HD / 16], int g) {
+#pragma unroll
+  for (int half = 0; half < HD / 64; ++half) {
+    bf16x8 lo, hi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      lo[r] = (bf16_t)o[4 * half + 0][r];
+      lo[4 + r] = (bf16_t)o[4 * half + 1][r];
+      hi[r] = (bf16_t)o[4 * half + 2][r];
+      hi[4 + r] = (bf16_t)o[4 * half + 3][r];
+    }
+    bf16_t* d = row + 64 * half + 16 * g;
+    *reinterpret_cast<bf16x8*>(d) = lo;
+    *reinterpret_cast<bf16x8*>(d + 8) = hi;
+  }
+}
+
 template <int HD, bool PLAIN>            // PLAIN: no mask, no dropout (compiled out)
 __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -645,23 +670,31 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
   const int q4 = qi >> 2, p4 = qi & 3;
   const int vrow0 = im.slot(slot_key(4 * g + q4, t0, h, L)), vrow1 = im.slot(slot_key(16 + 4 * g + q4, t0, h, L));
   bf16_t* orow = reinterpret_cast<bf16_t*>(a.out) + (tok0 + si.i) * (long)D + head * HD;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  f32x4 oo[HD / 16];
 #pragma unroll
   for (int dt = 0; dt < HD / 16; ++dt) {
-    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsV + vrow0 * RS + (16 * dt + 4 * p4) * 2));
-    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsV + vrow1 * RS + (16 * dt + 4 * p4) * 2));
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const int coff = (HD % 64 == 0 ? tr_col(dt, p4) : 16 * dt + 4 * p4) * 2;
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsV + vrow0 * RS + coff));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsV + vrow1 * RS + coff));
     s16x8 vv;
     vv[0] = lo4[0]; vv[1] = lo4[1]; vv[2] = lo4[2]; vv[3] = lo4[3];
     vv[4] = hi4[0]; vv[5] = hi4[1]; vv[6] = hi4[2]; vv[7] = hi4[3];
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, o, 0, 0, 0);
+    oo[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vv), pf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
 #ifdef FAVIT_PROBE
-    if (qvalid && (a.dbg != 2 || o[0] == 12345.f)) {
+  if (qvalid && (a.dbg != 2 || oo[0][0] == 12345.f)) {
 #else
-    if (qvalid) {
+  if (qvalid) {
 #endif
-      bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
-      *reinterpret_cast<bf16x4*>(orow + 16 * dt + 4 * g) = ob;
+    if constexpr (HD % 64 == 0) {
+      store_rows16<HD>(orow, oo, g);
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        bf16x4 ob = {(bf16_t)oo[dt][0], (bf16_t)oo[dt][1], (bf16_t)oo[dt][2], (bf16_t)oo[dt][3]};
+        *reinterpret_cast<bf16x4*>(orow + 16 * dt + 4 * g) = ob;
+      }
     }
   }
 }
@@ -1101,18 +1134,33 @@ __global__ __launch_bounds__(256) void mhla_bwd_mfma2_kernel(AttnArgs a) {
       const bool own = i >= r0 && i < r1;
       const int vrow0 = imK.slot_safe(slot_key(4 * g + q4, t0, h, L)), vrow1 = imK.slot_safe(slot_key(16 + 4 * g + q4, t0, h, L));
       bf16_t* dqrow = dqkv + (tok0 + si.i) * ld + head * HD;
+      if constexpr (HD % 64 == 0) {
+        f32x4 oq[HD / 16];
 #pragma unroll
-      for (int dt = 0; dt < HD / 16; ++dt) {
-        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + vrow0 * RS + (16 * dt + 4 * p4) * 2));
-        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + vrow1 * RS + (16 * dt + 4 * p4) * 2));
-        s16x8 kk;
-        kk[0] = lo4[0]; kk[1] = lo4[1]; kk[2] = lo4[2]; kk[3] = lo4[3];
-        kk[4] = hi4[0]; kk[5] = hi4[1]; kk[6] = hi4[2]; kk[7] = hi4[3];
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kk), dsf, o, 0, 0, 0);
-        if (own && !(probe_nostore && o[0] != 12345.f)) {
-          bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
-          *reinterpret_cast<bf16x4*>(dqrow + 16 * dt + 4 * g) = ob;
+        for (int dt = 0; dt < HD / 16; ++dt) {
+          const int coff = tr_col(dt, p4) * 2;
+          const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + vrow0 * RS + coff));
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + vrow1 * RS + coff));
+          s16x8 kk;
+          kk[0] = lo4[0]; kk[1] = lo4[1]; kk[2] = lo4[2]; kk[3] = lo4[3];
+          kk[4] = hi4[0]; kk[5] = hi4[1]; kk[6] = hi4[2]; kk[7] = hi4[3];
+          oq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kk), dsf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        if (own && !(probe_nostore && oq[0][0] != 12345.f)) store_rows16<HD>(dqrow, oq, g);
+      } else {
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+          const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + vrow0 * RS + (16 * dt + 4 * p4) * 2));
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + vrow1 * RS + (16 * dt + 4 * p4) * 2));
+          s16x8 kk;
+          kk[0] = lo4[0]; kk[1] = lo4[1]; kk[2] = lo4[2]; kk[3] = lo4[3];
+          kk[4] = hi4[0]; kk[5] = hi4[1]; kk[6] = hi4[2]; kk[7] = hi4[3];
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+          o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kk), dsf, o, 0, 0, 0);
+          if (own && !(probe_nostore && o[0] != 12345.f)) {
+            bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+            *reinterpret_cast<bf16x4*>(dqrow + 16 * dt + 4 * g) = ob;
+          }
         }
       }
     }
@@ -1223,9 +1271,10 @@ __global__ __launch_bounds__(256) void mhla_bwd_mfma2_kernel(AttnArgs a) {
   const bool jvalid = j < r1;
   bf16_t* dkrow = dqkv + (tok0 + jc) * ld + D + head * HD;
   bf16_t* dvrow = dkrow + D;
+  f32x4 okk[HD / 16], ovv[HD / 16];
 #pragma unroll
   for (int dt = 0; dt < HD / 16; ++dt) {
-    const int coff = (16 * dt + 4 * p4) * 2;
+    const int coff = (HD % 64 == 0 ? tr_col(dt, p4) : 16 * dt + 4 * p4) * 2;
     const s16x4 qa = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsQ + ta * RS + coff));
     const s16x4 qb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsQ + tb * RS + coff));
     const s16x4 ga = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsG + ta * RS + coff));
@@ -1233,14 +1282,21 @@ __global__ __launch_bounds__(256) void mhla_bwd_mfma2_kernel(AttnArgs a) {
     s16x8 qq, gg;
     qq[0] = qa[0]; qq[1] = qa[1]; qq[2] = qa[2]; qq[3] = qa[3]; qq[4] = qb[0]; qq[5] = qb[1]; qq[6] = qb[2]; qq[7] = qb[3];
     gg[0] = ga[0]; gg[1] = ga[1]; gg[2] = ga[2]; gg[3] = ga[3]; gg[4] = gb[0]; gg[5] = gb[1]; gg[6] = gb[2]; gg[7] = gb[3];
-    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
-    dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qq), wds, dk, 0, 0, 0);
-    dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gg), wp, dv, 0, 0, 0);
-    if (jvalid && !(probe_nostore && dk[0] != 12345.f)) {
-      bf16x4 kb4 = {(bf16_t)dk[0], (bf16_t)dk[1], (bf16_t)dk[2], (bf16_t)dk[3]};
-      bf16x4 vb4 = {(bf16_t)dv[0], (bf16_t)dv[1], (bf16_t)dv[2], (bf16_t)dv[3]};
-      *reinterpret_cast<bf16x4*>(dkrow + 16 * dt + 4 * g) = kb4;
-      *reinterpret_cast<bf16x4*>(dvrow + 16 * dt + 4 * g) = vb4;
+    okk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qq), wds, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    ovv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gg), wp, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+  if (jvalid && !(probe_nostore && okk[0][0] != 12345.f)) {
+    if constexpr (HD % 64 == 0) {
+      store_rows16<HD>(dkrow, okk, g);
+      store_rows16<HD>(dvrow, ovv, g);
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        bf16x4 kb4 = {(bf16_t)okk[dt][0], (bf16_t)okk[dt][1], (bf16_t)okk[dt][2], (bf16_t)okk[dt][3]};
+        bf16x4 vb4 = {(bf16_t)ovv[dt][0], (bf16_t)ovv[dt][1], (bf16_t)ovv[dt][2], (bf16_t)ovv[dt][3]};
+        *reinterpret_cast<bf16x4*>(dkrow + 16 * dt + 4 * g) = kb4;
+        *reinterpret_cast<bf16x4*>(dvrow + 16 * dt + 4 * g) = vb4;
+      }
     }
   }
 }
