@@ -85,6 +85,15 @@ template <> struct Mma<float> {
 
 typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr_t;
 
+// Column (relative to d0) that MFMA row group p4 of output tile dt covers in the bf16 path.  With 4 or 8 tiles the
+// tiles are interleaved (tile 4*half + sub holds columns 64 half + 16 (m/4) + 4 sub + m%4) so that lane group g ends up
+// with the 16 consecutive columns 64 half + 16 g .. + 15 and stores them as two 16-byte pieces; a
+// ds_read_b64_tr_b16 lane supplies its own column address, so the permutation is free.
+template <int NDT>
+__device__ __forceinline__ int tile_col(int dt, int p4) {
+  return NDT % 4 == 0 ? 64 * (dt >> 2) + 16 * p4 + 4 * (dt & 3) : 16 * dt + 4 * p4;
+}
+
 // acc[dt] (+)= X^T[d0 + 16 dt ..][rows of the block] . w   with w = the lane's 8 values (sub-tile st = e >> 2,
 // row 4g + (e & 3)) of its owner column.  tile = LDS image of the 32 streamed rows (row stride rs bytes).
 template <typename T, int NDT>
@@ -96,12 +105,13 @@ __device__ __forceinline__ void acc_transposed(f32x4 (&acc)[NDT], const char* ti
 #pragma unroll
     for (int e = 0; e < 8; ++e) wf[e] = (bf16_t)w[e];
     const int q4 = n >> 2, p4 = n & 3;
-    const char* r0 = tile + (4 * g + q4) * rs + (d0 + 4 * p4) * 2;
-    const char* r1 = tile + (16 + 4 * g + q4) * rs + (d0 + 4 * p4) * 2;
+    const char* r0 = tile + (4 * g + q4) * rs + d0 * 2;
+    const char* r1 = tile + (16 + 4 * g + q4) * rs + d0 * 2;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-      const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(r0 + 32 * dt));
-      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(r1 + 32 * dt));
+      const int coff = tile_col<NDT>(dt, p4) * 2;
+      const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(r0 + coff));
+      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr_t)(r1 + coff));
       typedef __attribute__((ext_vector_type(8))) short s16x8;
       s16x8 xx;
       xx[0] = lo4[0]; xx[1] = lo4[1]; xx[2] = lo4[2]; xx[3] = lo4[3];
@@ -253,44 +263,52 @@ __global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
     }
   }
 
-  // ---- store: the lane holds, for owner row `on`, columns d0 + 16 dt + 4g .. + 3 ----
+  // ---- store: the lane holds, for owner row `on`, columns d0 + 16 dt + 4g .. + 3 (fp32, or fewer than 4 tiles),
+  //      or the 16 consecutive columns d0 + 64 half + 16 g .. of tiles 4 half .. 4 half + 3 (bf16, see tile_col) ----
+  auto store = [&](void* base, const View& vw, const f32x4 (&acc)[NDT], float mul) {
+    T* orow = reinterpret_cast<T*>(base) + b * vw.sb + h * vw.sh + (long)on * vw.ld;
+    if constexpr (sizeof(T) == 2 && NDT % 4 == 0) {
+#pragma unroll
+      for (int half = 0; half < NDT / 4; ++half) {
+        const int d = d0 + 64 * half + 16 * g;
+        if (d < hd) {
+          bf16x8 lo, hi;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            lo[r] = (bf16_t)(acc[4 * half + 0][r] * mul);
+            lo[4 + r] = (bf16_t)(acc[4 * half + 1][r] * mul);
+            hi[r] = (bf16_t)(acc[4 * half + 2][r] * mul);
+            hi[4 + r] = (bf16_t)(acc[4 * half + 3][r] * mul);
+          }
+          *reinterpret_cast<bf16x8*>(orow + d) = lo;
+          *reinterpret_cast<bf16x8*>(orow + d + 8) = hi;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int d = d0 + 16 * dt + 4 * g;
+        if (d < hd) {
+          if constexpr (sizeof(T) == 2) {
+            bf16x4 ob = {(bf16_t)(acc[dt][0] * mul), (bf16_t)(acc[dt][1] * mul), (bf16_t)(acc[dt][2] * mul), (bf16_t)(acc[dt][3] * mul)};
+            *reinterpret_cast<bf16x4*>(orow + d) = ob;
+          } else {
+            *reinterpret_cast<float4*>(orow + d) = make_float4(acc[dt][0] * mul, acc[dt][1] * mul, acc[dt][2] * mul, acc[dt][3] * mul);
+          }
+        }
+      }
+    }
+  };
   if (MODE == 0) {
     l_run = quad16_sum(l_run);
     const float inv = 1.0f / l_run;                    // a fully masked row: 0 * inf = NaN, as torch's softmax
     if (on < Lo) {
-      T* orow = reinterpret_cast<T*>(a.out0) + b * a.vo0.sb + h * a.vo0.sh + (long)on * a.vo0.ld;
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        const int d = d0 + 16 * dt + 4 * g;
-        if (d < hd) {
-          if constexpr (sizeof(T) == 2) {
-            bf16x4 ob = {(bf16_t)(acc1[dt][0] * inv), (bf16_t)(acc1[dt][1] * inv), (bf16_t)(acc1[dt][2] * inv), (bf16_t)(acc1[dt][3] * inv)};
-            *reinterpret_cast<bf16x4*>(orow + d) = ob;
-          } else {
-            *reinterpret_cast<float4*>(orow + d) = make_float4(acc1[dt][0] * inv, acc1[dt][1] * inv, acc1[dt][2] * inv, acc1[dt][3] * inv);
-          }
-        }
-      }
+      store(a.out0, a.vo0, acc1, inv);
       if (g == 0 && blockIdx.z == 0) a.lse[zq + on] = m_run + __logf(l_run);
     }
   } else if (on < Lo) {
-    auto store = [&](void* base, const View& vw, const f32x4 (&acc)[NDT]) {
-      T* orow = reinterpret_cast<T*>(base) + b * vw.sb + h * vw.sh + (long)on * vw.ld;
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        const int d = d0 + 16 * dt + 4 * g;
-        if (d < hd) {
-          if constexpr (sizeof(T) == 2) {
-            bf16x4 ob = {(bf16_t)acc[dt][0], (bf16_t)acc[dt][1], (bf16_t)acc[dt][2], (bf16_t)acc[dt][3]};
-            *reinterpret_cast<bf16x4*>(orow + d) = ob;
-          } else {
-            *reinterpret_cast<float4*>(orow + d) = make_float4(acc[dt][0], acc[dt][1], acc[dt][2], acc[dt][3]);
-          }
-        }
-      }
-    };
-    store(a.out0, a.vo0, acc0);
-    if (MODE == 2) store(a.out1, a.vo1, acc1);
+    store(a.out0, a.vo0, acc0, 1.0f);
+    if (MODE == 2) store(a.out1, a.vo1, acc1, 1.0f);
   }
 }
 
