@@ -537,6 +537,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_glds_kernel(KParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#ifdef FAVIT_PROBE
+  // dbg 16: stagger experiment -- one of the two first-round workgroups of a CU starts (dbg >> 8) us late, so that its
+  // epilogue (HBM) falls on the other's main loop (L2 -> LDS + MFMA).  bit 5 selects the guess of which blocks share a CU.
+  if ((p.dbg & 16) && blockIdx.x < 512 && blockIdx.y == 0 && blockIdx.z == 0) {
+    const int idx = blockIdx.x >> 3;
+    const bool late = (p.dbg & 32) ? (idx & 1) : ((idx >> 5) & 1);
+    if (late) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      const unsigned long long ticks = (unsigned long long)(p.dbg >> 8) * 100ull;
+      while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+#endif
   const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0) && (wc == 0);
   f32x4 racc[4];
 #pragma unroll

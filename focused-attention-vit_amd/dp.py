@@ -6,8 +6,10 @@ the gradient all-reduce after ``loss.backward()`` (every image is independent: n
 no cross-sample op).  Design for xGMI (7 point-to-point links per GPU, no switch):
   * gradients live in ONE flat fp32 buffer per parameter group (``.grad`` tensors are views),
     so a bucket is a slice -- no gather/scatter copies around the collective;
-  * few, large buckets (default 32 MiB): on a fully connected 8-GPU node RCCL's all-reduce is
-    per-link bound, so large messages amortise the per-collective launch + latency;
+  * few, large buckets: on a fully connected 8-GPU node RCCL's all-reduce is per-link bound, so large
+    messages amortise the per-collective launch + latency -- but the LAST bucket (patch embedding + first
+    block) cannot overlap with anything, so the default is an eighth of the gradient bytes, clamped to
+    4..32 MiB (ViT-MHLA-Small: 88 MB of gradients -> 8 buckets of ~11 MiB; ViT-Base: 32 MiB);
   * a bucket's all-reduce is issued (async, on RCCL's own stream) as soon as every parameter in it
     has reported a gradient (a set of parameters, not a count of events: a parameter used twice in
     one forward reports twice), which overlaps it with the rest of backward.  Gradient accumulation
@@ -62,9 +64,13 @@ class FlatBuffers:
 class GradSync:
     """Bucketed, overlapped all-reduce (mean) of a FlatBuffers' gradient buffer."""
 
-    def __init__(self, flat: FlatBuffers, bucket_mb: float = 32.0, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, flat: FlatBuffers, bucket_mb: Optional[float] = None,
+                 group: Optional[dist.ProcessGroup] = None):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if bucket_mb is None:
+            bucket_mb = min(32.0, max(4.0, flat.numel * 4 / (1 << 20) / 8))
+        self.bucket_mb = bucket_mb
         cap = max(1, int(bucket_mb * (1 << 20) / 4))
         # bucket boundaries on parameter boundaries
         self.buckets = []          # (start, end, [param indices])

@@ -62,7 +62,7 @@ class FusedAdamW:
     parameter / gradient / moment buffers (and the DP all-reduce runs on the same flat
     gradient buffers, see dp.py)."""
 
-    def __init__(self, groups, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, bucket_mb=32.0,
+    def __init__(self, groups, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, bucket_mb=None,
                  distributed=None):
         if isinstance(groups, torch.nn.Module):
             groups = [{"params": list(groups.parameters())}]
