@@ -175,3 +175,39 @@ extern "C" int probe_dma_share(const void* A, const void* W, long a_tile_bytes, 
                      a_tile_bytes, w_tile_bytes, ntile, ksteps, mode, (unsigned*)census, sink);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---- what the matrix cores deliver on this device under load: a bare v_mfma_f32_16x16x32_bf16 loop ----
+// Every wave keeps `NACC` independent accumulators and issues MFMAs back to back on register operands (random bf16
+// data, no memory traffic in the loop).  out[block] = {shader cycles, 100 MHz ticks} of wave 0 around the loop, so
+// the host can report the clock the chip held (guide: "DVFS give-back" item 6).
+typedef __attribute__((ext_vector_type(8))) __bf16 pbf16x8;
+typedef __attribute__((ext_vector_type(4))) float pf32x4;
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(const pbf16x8* __restrict__ seed, int iters, unsigned long long* out,
+                                                        float* sink) {
+  const int tid = threadIdx.x;
+  pbf16x8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = seed[(tid * 8 + i) & 4095]; b[i] = seed[(tid * 8 + 4 + i) & 4095]; }
+  pf32x4 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678f) sink[0] = s;
+  if (tid == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+extern "C" int probe_mfma_peak(const void* seed, int iters, int blocks, void* out, void* sink, void* stream) {
+  hipLaunchKernelGGL(mfma_peak_kernel<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const pbf16x8*)seed, iters,
+                     (unsigned long long*)out, (float*)sink);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
