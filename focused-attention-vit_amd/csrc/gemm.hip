@@ -65,6 +65,7 @@ struct KParams {
   int xcd_split;       // 1: 1-D grid of ntiles*nsplit blocks, all tiles of a split on one XCD
   int store_policy;    // cache policy of the epilogue's output stores (store16_policy)
   int rowsum_store;    // 1: a_rowsum is a private slab slot of this split (plain store), 0: atomicAdd
+  int q_block0, q_tile0;   // p4: blocks >= q_block0 (> 0) run 64x128 quarter tiles of the full tiles from q_tile0 on
 #ifdef FAVIT_PROBE
   int dbg;     // probe build only (make probe; tools/): 1 = skip epilogue, 2 = skip main loop
   unsigned long long* probe;   // probe build only: per-wave cycle stamps of the pp kernel (favit_probe_buffer)
@@ -537,19 +538,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_glds_kernel(KParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#ifdef FAVIT_PROBE
-  // dbg 16: stagger experiment -- one of the two first-round workgroups of a CU starts (dbg >> 8) us late, so that its
-  // epilogue (HBM) falls on the other's main loop (L2 -> LDS + MFMA).  bit 5 selects the guess of which blocks share a CU.
-  if ((p.dbg & 16) && blockIdx.x < 512 && blockIdx.y == 0 && blockIdx.z == 0) {
-    const int idx = blockIdx.x >> 3;
-    const bool late = (p.dbg & 32) ? (idx & 1) : ((idx >> 5) & 1);
-    if (late) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      const unsigned long long ticks = (unsigned long long)(p.dbg >> 8) * 100ull;
-      while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-    }
-  }
-#endif
   const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0) && (wc == 0);
   f32x4 racc[4];
 #pragma unroll
@@ -640,6 +628,8 @@ constexpr int P4_A_BYTES = 256 * 64;               // 16 KiB
 constexpr int P4_B_BYTES = 128 * 64;               // 8 KiB
 constexpr int P4_STAGE = P4_A_BYTES + P4_B_BYTES;  // 24 KiB
 constexpr int P4_LDS = 3 * P4_STAGE;               // 73728
+constexpr int S64_A_BYTES = 64 * 128;                // A image of the 64-row tiles (BK = 64): 8 KiB
+constexpr int S64_STAGE = S64_A_BYTES + OP16_BYTES;  // 24 KiB
 
 __device__ __forceinline__ int ksw32(int row) { return (-(row >> 2)) & 3; }
 
@@ -882,6 +872,25 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
 #else
   const int nk = (int)((kend - kbeg) / SBK);
 #endif
+#ifdef FAVIT_PROBE
+  // dbg 16: stagger experiment -- one of the two first-round workgroups of a CU starts (dbg >> 8) us late, so that its
+  // epilogue (HBM) falls on the other's main loop (L2 -> LDS + MFMA).  bit 5 selects the guess of which blocks share a CU.
+  if ((p.dbg & 16) && blockIdx.x < 512 && blockIdx.y == 0 && blockIdx.z == 0) {
+    const int idx = blockIdx.x >> 3;
+    const bool late = (p.dbg & 32) ? (idx & 1) : ((idx >> 5) & 1);
+    if (late) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      const unsigned long long ticks = (unsigned long long)(p.dbg >> 8) * 100ull;
+      while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+#endif
+#ifdef FAVIT_PROBE
+  // dbg 128 + probe buffer: per-workgroup timeline [block][4] = {start, main loop done, end} in 10-ns ticks + placement
+  const bool tl = (p.dbg & 128) && p.probe && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+  unsigned long long tl0 = 0, tl1 = 0;
+  if (tl) tl0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0) && (wc == 0);
   f32x4 racc[4];
 #pragma unroll
@@ -1007,12 +1016,100 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
     if (p.scale_b) alpha *= p.scale_b[0];
   }
   __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
+#ifdef FAVIT_PROBE
+  if (tl) tl1 = __builtin_amdgcn_s_memrealtime();
+#endif
   wave_epilogue<bf16_t, OutT>(p, acc, C, m0 + wr * 64, n0 + wc * 64, lane,
                               reinterpret_cast<float*>(smem + wave * WEPI_BYTES), split == 0, alpha);
+#ifdef FAVIT_PROBE
+  if (p.dbg & 128) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
+    if (tl) {
+      const unsigned long long tl2 = __builtin_amdgcn_s_memrealtime();
+      const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+      unsigned long long* o = p.probe + (size_t)blockIdx.x * 4;
+      o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = ((unsigned long long)(xcc & 0xF) << 32) | hw;
+    }
+  }
+#endif
+}
+
+// The tail of a p4 launch as quarter tiles.  T tiles on 512 workgroup slots leave T mod 512 tiles for a last round
+// that occupies a fraction of the CUs for a whole tile time, one latency-bound workgroup per CU (the N = 384 GEMMs
+// of the step: 591 tiles, the last 79 alone on the chip for 38 % of the launch).  A latency-bound tile's time is
+// its number of k-steps, not its rows, so those tiles are issued as four 64x128 quarters each with 64-deep stages
+// (half the barriers; the 24-KiB stage of the 64-row kernel, which is exactly a p4 stage): 8 waves as 4x2 of 16x64,
+// one A and two B DMA pieces per wave and stage, the wave-private epilogue of the full tile.  k-major A, K % 64 == 0.
+template <bool BKM, typename OutT>
+__device__ __forceinline__ void p4_quarter_body(const KParams& p, int q) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(S64_STAGE == P4_STAGE, "the quarter tiles reuse the stage buffers of the full tiles");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int t = p.q_tile0 + (q >> 2);
+  const long m0 = (long)(t / p.tiles_n) * P4_BM + 64 * (q & 3);
+  const long n0 = (long)(t % p.tiles_n) * BN;
+  if (m0 >= p.M) return;                              // uniform for the workgroup, before any barrier
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B);
+  OutT* C = reinterpret_cast<OutT*>(p.C);
+  const int nk = (int)(p.K / BK16);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bf16_t* sa = glds_src<true>(A, p.lda, m0, p.M, 0, wave, lane);
+  const bf16_t* sb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) sb[j] = glds_src<BKM>(Bm, p.ldb, n0, p.N, 0, wave * 2 + j, lane);
+  auto issue = [&](int buf) {
+    char* st = smem + buf * S64_STAGE;
+    __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(st + wave * 1024), 16, 0, 0);
+    sa += BK16;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sb[j], (lptr_t)(st + S64_A_BYTES + (wave * 2 + j) * 1024), 16, 0, 0);
+      sb[j] += BKM ? BK16 : BK16 * p.ldb;
+    }
+  };
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);
+    const char* la = smem + cur * S64_STAGE;
+    const char* lb = la + S64_A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 af = load_frag16<true>(la, wr * 16, ks, lane);
+      bf16x8 bfr[4];
+      load_frags4<BKM, false>(lb, wc * 64, ks, lane, bfr);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[0][j], 0, 0, 0);
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
+  wave_epilogue_rows<bf16_t, OutT, 0, 1>(p, acc, C, m0 + wr * 16, n0 + wc * 64, lane,
+                                         reinterpret_cast<float*>(smem + wave * WEPI_BYTES), true, p.alpha);
 }
 
 template <bool AK, bool BKM, typename OutT>
 __global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_kernel(KParams p) {
+  if constexpr (AK) {
+    if (p.q_block0 > 0) {
+      // (quarter tiles FIRST instead -- finishing early, staggering the full tiles behind them -- measured the same)
+      const int b = (int)blockIdx.x;
+      if (b >= p.q_block0) p4_quarter_body<BKM, OutT>(p, xcd_remap(b - p.q_block0, (int)gridDim.x - p.q_block0));
+      else p4_body<AK, BKM, OutT>(p, xcd_remap(b, p.q_block0), 0, 0);
+      return;
+    }
+  }
   int tile, split;
   tile_and_split(p, tile, split);
   p4_body<AK, BKM, OutT>(p, tile, split, blockIdx.z);
@@ -1375,8 +1472,6 @@ int launch_p7(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
 // (The opposite choice -- the 256x128 kernel on these problems -- measured 4.68 -> 5.44 ms per SPPP step.)
 // --------------------------------------------------------------------------------------
 constexpr int S64_BM = 64;
-constexpr int S64_A_BYTES = 64 * 128;                    // 8 KiB
-constexpr int S64_STAGE = S64_A_BYTES + OP16_BYTES;      // 24 KiB
 constexpr int S64_LDS = 3 * S64_STAGE;                   // 73728
 
 template <bool BKM, typename OutT>
@@ -1526,8 +1621,14 @@ __global__ __launch_bounds__(256) void grouped_reduce_kernel(ReduceParams rp) {
 
 template <typename Kn>
 int launch_p4(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
-  favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), P4_LDS);
-  hipLaunchKernelGGL(kernel, grid, dim3(P4_THREADS), P4_LDS, st, kp);
+#ifdef FAVIT_PROBE
+  // FAVIT_GEMM_P4_ONE_PER_CU: claim 100 KiB of LDS so that only one workgroup fits a CU (occupancy experiment)
+  static const int lds_bytes = getenv("FAVIT_GEMM_P4_ONE_PER_CU") ? 100 * 1024 : P4_LDS;
+#else
+  constexpr int lds_bytes = P4_LDS;
+#endif
+  favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), lds_bytes);
+  hipLaunchKernelGGL(kernel, grid, dim3(P4_THREADS), lds_bytes, st, kp);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }
@@ -1721,7 +1822,8 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 // same result; the work-skipping probe switch (FAVIT_GEMM_DBG) exists only in the `make probe` build.
 struct GemmKnobs {
   int dbg, store_policy;
-  bool force128, no_p4, no_p7, no_s64, no_pp;
+  bool force128, no_p4, no_p7, no_s64, no_pp, no_quarter;
+  long quarter_max;
   GemmKnobs() {
     const char* e;
 #ifdef FAVIT_PROBE
@@ -1735,6 +1837,8 @@ struct GemmKnobs {
     no_p7 = getenv("FAVIT_GEMM_NO_P7") != nullptr;
     no_s64 = getenv("FAVIT_GEMM_NO_S64") != nullptr;
     no_pp = getenv("FAVIT_GEMM_NO_PP") != nullptr;
+    no_quarter = getenv("FAVIT_GEMM_NO_QUARTER") != nullptr;
+    quarter_max = (e = getenv("FAVIT_GEMM_QUARTER_MAX")) ? atol(e) : 128;       // tail rounds up to 25 % of the slots
   }
 };
 static const GemmKnobs& knobs() {
@@ -1833,6 +1937,8 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.tiles_n = (int)tiles_n;
   kp.ntiles = (int)(tiles_m * tiles_n);
   kp.xcd_split = 0;
+  kp.q_block0 = 0;
+  kp.q_tile0 = 0;
   kp.alpha = g->alpha;
   kp.scale_a = fp8 ? g->scale_a : nullptr;
   kp.scale_b = fp8 ? g->scale_b : nullptr;
@@ -1936,6 +2042,15 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
     if (xcd_split) {
       kp.xcd_split = 1;
       grid4 = dim3((unsigned)(t4 * splits), 1u, 1u);
+    }
+    // tail round as quarter tiles (p4_quarter_body): single-pass, un-batched, k-major A, a last round that would
+    // leave more than 40 % of the 512 workgroup slots empty
+    const long tail4 = t4 % 512;
+    if (!knobs().no_quarter && g->a_kmajor && splits == 1 && batch == 1 && !atomic && t4 > 512 && tail4 > 0 &&
+        tail4 <= knobs().quarter_max && (g->K % BK16) == 0) {
+      kp.q_block0 = (int)(t4 - tail4);
+      kp.q_tile0 = (int)(t4 - tail4);
+      grid4 = dim3((unsigned)(t4 - tail4 + 4 * tail4), 1u, 1u);
     }
     if (g->out_dtype == FAVIT_BF16) {
       switch (layout) {

@@ -345,12 +345,13 @@ def flush_wgrads() -> None:
         return
     _WG["list"] = [] if lst is not None else None
     probs = [(dy, a, dw, db, acc) for dy, a, dw, db, acc, _ in lst]
-    if len(probs) < 2 or not K.gemm_grouped_tn(probs):
-        for dy, a, dw, db, acc in probs:
-            K.gemm(dy, a, dw, dy.shape[1], a.shape[1], dy.shape[0], dy.stride(0), a.stride(0), dw.stride(0),
-                   a_kmajor=False, b_kmajor=False, a_rowsum=db, accumulate=acc)
-    for *_, ready in lst:
-        _ready(*ready)
+    with _side_stream(*[t for pr in probs for t in pr[:4]]):
+        if len(probs) < 2 or not K.gemm_grouped_tn(probs):
+            for dy, a, dw, db, acc in probs:
+                K.gemm(dy, a, dw, dy.shape[1], a.shape[1], dy.shape[0], dy.stride(0), a.stride(0), dw.stride(0),
+                       a_kmajor=False, b_kmajor=False, a_rowsum=db, accumulate=acc)
+        for *_, ready in lst:
+            _ready(*ready)
 
 
 def end_wgrads() -> None:
@@ -818,13 +819,15 @@ class EncoderOp:
                 if dg1 is None:
                     _ready(g1, b1)
                 flush_wgrads()
-                join_side_stream()
+                if not _SIDE["enabled"]:
+                    join_side_stream()
                 grads = [dg1, db1] + ga + [dg2, db2] + gm + grads
         except BaseException:
             _WG["list"] = None                # drop the half-collected weight gradients of the failed backward
             _SIDE["pending"].clear()
             raise
         end_wgrads()
+        join_side_stream()
         return [g.reshape(B, L, D)], grads
 
 

@@ -580,6 +580,50 @@ def test_gemm_ping_pong_kernel(K, bk, M, N, Kd, forced, out_dtype, epi, monkeypa
     assert rel_l2(out.float(), ref) < (1e-2 if out_dtype == torch.bfloat16 else 2e-5)
 
 
+@pytest.mark.parametrize("bk", [True, False])
+@pytest.mark.parametrize("M,N,Kd", [(50432, 384, 384), (50432 + 100, 384, 1536), (45000 - 8, 1152, 128), (131072 + 64 * 3 + 5, 200, 64)])
+@pytest.mark.parametrize("out_dtype,epi", [(torch.bfloat16, "gelu"), (torch.bfloat16, "dgelu"), (torch.float32, "res")])
+def test_gemm_quarter_tile_tail(K, bk, M, N, Kd, out_dtype, epi):
+    """256x128-tile launches whose last round would fill at most 60 % of the 512 workgroup slots run that round as
+    64x128 quarter tiles (blocks past the full rounds): the benchmark's N = 384 GEMMs (591 tiles = 512 + 79), a
+    ragged M whose last panel is a partial quarter, a multi-round launch (1584 = 3 * 512 + 48 tiles), a ragged N;
+    both B layouts and the fused epilogues."""
+    if not bk and N % 8:
+        pytest.skip("mn-major DMA images need N % 8 == 0")
+    t4 = ((M + 255) // 256) * ((N + 127) // 128)
+    assert t4 > 512 and 0 < t4 % 512 <= 307            # the shapes above must reach the quarter-tile path
+    g = torch.Generator(device=DEV).manual_seed(M % 1000 + N + Kd)
+    a = _rand((M, Kd), torch.bfloat16, g)
+    b = _rand((N, Kd) if bk else (Kd, N), torch.bfloat16, g)
+    bias = _rand((N,), torch.float32, g)
+    out = torch.empty((M, N), dtype=out_dtype, device=DEV)
+    ref = a.float() @ (b.float().t() if bk else b.float())
+    kw = dict(b_kmajor=bk)
+    ldb = Kd if bk else N
+    if epi == "gelu":
+        pre = torch.empty_like(out)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, bias=bias, act=_abi().ACT_GELU, aux_out=pre, ld_aux_out=N, **kw)
+        ref = ref + bias
+        assert rel_l2(pre.float(), ref) < 1e-2
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == "dgelu":
+        pre = _rand((M, N), torch.bfloat16, g)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, act=_abi().ACT_DGELU, aux_in=pre, ld_aux_in=N, **kw)
+        x = pre.float().requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        ref = ref * x.grad
+    else:
+        res = _rand((M, N), torch.float32, g)
+        K.gemm(a, b, out, M, N, Kd, Kd, ldb, N, bias=bias, residual=res, ld_res=N, **kw)
+        ref = ref + bias + res
+    tol = 1e-2 if out_dtype == torch.bfloat16 else 2e-5
+    assert rel_l2(out.float(), ref) < tol
+    # the tail rows on their own (a wrong quarter mapping would hide in the whole-matrix norm)
+    tail_rows = slice((M // 256 - 30) * 256, M)
+    assert rel_l2(out[tail_rows].float(), ref[tail_rows]) < tol
+    assert torch.isfinite(out.float()).all()
+
+
 # ---------------------------------------------------------------------------------------------
 # Seeded random sweeps: every dispatch branch of favit_gemm (register-staged / DMA 128x128 / 256x128 /
 # 256x256 / split-K / fp32) is reached by some shape below; ragged sizes and odd leading dimensions.
