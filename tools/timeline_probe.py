@@ -29,12 +29,19 @@ cases = [
 ]
 for name, fn, tiles in cases:
     buf = torch.zeros(tiles * 4, dtype=torch.int64, device=dev)
-    for _ in range(3): fn()
-    torch.cuda.synchronize()
+    # sustained conditions: the stamped launch follows 40 back-to-back launches without a sync (the chip lowers its
+    # clock under MFMA load; a launch after an idle gap runs ~25 % faster and is not representative)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    for _ in range(10): fn()
+    e0.record()
+    for _ in range(30): fn()
+    e1.record()
     lib.favit_probe_buffer(ctypes.c_void_p(buf.data_ptr()))
     fn()
+    e2.record()
     torch.cuda.synchronize()
     lib.favit_probe_buffer(None)
+    print(f"[{name}] back-to-back average {e0.elapsed_time(e1) / 30 * 1e3:.1f} us, the stamped launch {e1.elapsed_time(e2) * 1e3:.1f} us (events)")
     t = buf.view(tiles, 4).cpu().numpy()
     t0, t1, t2, hw = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
     base = t0.min()
