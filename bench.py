@@ -166,6 +166,9 @@ def cpu_baseline(cfg, model, segs_np):
 
 
 def main():
+    if os.environ.get("FAVIT_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["FAVIT_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

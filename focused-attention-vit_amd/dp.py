@@ -20,8 +20,21 @@ from __future__ import annotations
 
 from typing import Iterable, List, Optional
 
+import os
+import threading
+
 import torch
 import torch.distributed as dist
+
+# FAVIT_DP_DEBUG=<dir>: every rank appends its sequence of bucket launches / waits to <dir>/dp_rank<r>.log
+# (collectives must be issued in the same order on every rank; this is how a mismatch is found)
+_DEBUG = os.environ.get("FAVIT_DP_DEBUG")
+
+
+def _dbg(msg):
+    r = dist.get_rank() if dist.is_initialized() else 0
+    with open(os.path.join(_DEBUG, f"dp_rank{r}.log"), "a") as f:
+        f.write(msg + "\n")
 
 
 class FlatBuffers:
@@ -68,6 +81,7 @@ class GradSync:
                  group: Optional[dist.ProcessGroup] = None):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
         if bucket_mb is None:
             bucket_mb = min(32.0, max(4.0, flat.numel * 4 / (1 << 20) / 8))
         self.bucket_mb = bucket_mb
@@ -91,7 +105,7 @@ class GradSync:
         self._handles = []
         self._launched = [False] * len(self.buckets)
         self._hooks = []
-        self.defer = False
+        self.defer = bool(os.environ.get("FAVIT_DP_DEFER"))     # debugging aid: launch every bucket from finish()
         self._index = {id(p): i for i, p in enumerate(flat.params)}
         if self.world > 1:
             for i, p in enumerate(flat.params):
@@ -162,6 +176,16 @@ class GradSync:
         s, e, _ = self.buckets[b]
         buf = self.flat.flat_g[s:e]
         self._launched[b] = True
+        if _DEBUG:
+            _dbg(f"launch sync#{id(self) % 9973} bucket {b} [{s}:{e}) thread {threading.current_thread().name}")
+        if self._host_staged and buf.is_cuda:
+            # gloo stages device tensors through pinned host memory on pool streams that its worker threads
+            # synchronise.  With three or more ranks sharing ONE GPU (the only way to rehearse N ranks on a one-GPU
+            # box) such an op, issued while the compute stream still has work queued, intermittently never completes
+            # on any rank (identical launch sequences on all ranks: FAVIT_DP_DEBUG logs; gone with the stream drained
+            # first).  gloo is the rehearsal / test backend, so drain; nccl (RCCL) orders by stream events on the
+            # device and is launched without any host wait.
+            torch.cuda.current_stream().synchronize()
         self._handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf))
 
     def finish(self, average: bool = True):
@@ -171,8 +195,12 @@ class GradSync:
         if self.world > 1:
             for b in range(len(self.buckets)):
                 self._launch(b)
-            for h, _ in self._handles:
+            for k, (h, _) in enumerate(self._handles):
+                if _DEBUG:
+                    _dbg(f"wait sync#{id(self) % 9973} handle {k}/{len(self._handles)}")
                 h.wait()
+            if _DEBUG:
+                _dbg(f"done sync#{id(self) % 9973}")
             if average:
                 self.flat.flat_g.mul_(1.0 / self.world)
         self.reset()
