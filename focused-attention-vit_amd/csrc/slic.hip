@@ -12,12 +12,16 @@
 //            quantised to 1/16 units (int16 x 4 per pixel).  Float work: compared with a tolerance.
 //   stage 2  favit_slic_cluster  : k-means in (y, x, L, a, b), fixed point (1/16 pixel, 1/16 Lab), int64 distances
 //            16^2 * spatial^2 + coef * dq^2 with coef = round(step^2 / compactness^2), first-minimum ties, centres =
-//            truncated integer means.  One workgroup per image, centres and per-cluster sums in LDS, sums reduced
-//            per wave before the LDS atomics.  Integer work: bit-exact.
-//   stage 3  favit_slic_connect  : 4-connected components of the cluster map (min-index propagation with pointer
-//            jumping), components in raster order of their first pixel; those smaller than min_size take the label
-//            of an already-labelled neighbour of their first pixel (x+1, x-1, y+1, y-1; the last one found wins),
-//            the others get consecutive labels from 0.  Integer work: bit-exact.
+//            truncated integer means.  One assignment launch over every pixel of every image + one centre update per
+//            iteration (round 2 used one workgroup per image: 6.0 ms for 128 images of 224x224, half the chip idle);
+//            per-cluster sums reduced per wave, then per workgroup in LDS, then 64-bit global atomics.  Integer
+//            work: bit-exact, independent of the order of the atomics.
+//   stage 3  favit_slic_connect  : 4-connected components of the cluster map by union-find over every pixel in
+//            parallel (the smaller root wins, so a component's root is its smallest pixel index whatever the order of
+//            the unions; round 2 iterated min-propagation in one workgroup per image: 10.5 ms), components in raster
+//            order of their first pixel; those smaller than min_size take the label of an already-labelled neighbour
+//            of their first pixel (x+1, x-1, y+1, y-1; the last one found wins), the others get consecutive labels
+//            from 0.  Integer work: bit-exact.
 #include "common.h"
 
 namespace {
@@ -84,129 +88,174 @@ __device__ __forceinline__ int masked_wave_sum(int v, bool in) {
   return s;
 }
 
-__global__ __launch_bounds__(SLIC_THREADS) void slic_cluster_kernel(const short* __restrict__ feat, uint8_t* __restrict__ labels,
-                                                                    const int* __restrict__ init_yx, int K, int H, int W,
-                                                                    int step, long long coef, int iters) {
-  __shared__ int cen[SLIC_MAXK][5];      // y16, x16, l, a, b
-  __shared__ int sums[SLIC_MAXK][6];     // + count
-  __shared__ int changed;
+// ---- stage 2: k-means, one launch pair per iteration, every pixel of every image in parallel ----
+// workspace per image: sums[K][6] int64 (y16, x16, l, a, b, count), then cen[K][5] int32.  All sums are exact
+// integers, so the order in which workgroups add them does not matter: bit-identical to the one-workgroup-per-image
+// form this replaces (and to oracle/slic_oracle.py).  The old kernel stopped at the first iteration that changed no
+// label; further iterations of a fixed point reproduce it, so running all of them gives the same labels.
+__host__ __device__ __forceinline__ size_t slic_ws_stride(int K) {       // bytes per image, a multiple of 8
+  return (size_t)K * 48 + (((size_t)K * 20 + 7) & ~(size_t)7);
+}
+__device__ __forceinline__ long long* slic_sums(void* ws, int b, int K) {
+  return reinterpret_cast<long long*>(reinterpret_cast<char*>(ws) + (size_t)b * slic_ws_stride(K));
+}
+__device__ __forceinline__ int* slic_cen(void* ws, int b, int K) {
+  return reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (size_t)b * slic_ws_stride(K) + (size_t)K * 48);
+}
+
+__global__ __launch_bounds__(64) void slic_seed_kernel(const short* __restrict__ feat, const int* __restrict__ init_yx,
+                                                       void* ws, int K, int H, int W) {
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid >= K) return;
+  const short* f = feat + (long)b * H * W * 4;
+  const int cy = init_yx[2 * tid], cx = init_yx[2 * tid + 1];
+  const short* q = f + ((long)cy * W + cx) * 4;
+  int* cen = slic_cen(ws, b, K) + tid * 5;
+  cen[0] = cy * 16; cen[1] = cx * 16; cen[2] = q[0]; cen[3] = q[1]; cen[4] = q[2];
+  long long* sm = slic_sums(ws, b, K) + tid * 6;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) sm[c] = 0;
+}
+
+__global__ __launch_bounds__(SLIC_THREADS) void slic_assign_kernel(const short* __restrict__ feat, uint8_t* __restrict__ labels,
+                                                                   void* ws, int K, int H, int W, int step, long long coef) {
+  __shared__ int cen[SLIC_MAXK][5];      // y16, x16, l, a, b
+  __shared__ int sums[SLIC_MAXK][6];     // this workgroup's <= 1024 pixels: fits 32 bits
+  const int b = blockIdx.y, tid = threadIdx.x;
   const int HW = H * W;
   const short* f = feat + (long)b * HW * 4;
   uint8_t* lab = labels + (long)b * HW;
-  if (tid < K) {
-    const int cy = init_yx[2 * tid], cx = init_yx[2 * tid + 1];
-    const short* q = f + ((long)cy * W + cx) * 4;
-    cen[tid][0] = cy * 16; cen[tid][1] = cx * 16; cen[tid][2] = q[0]; cen[tid][3] = q[1]; cen[tid][4] = q[2];
-  }
-  for (int p = tid; p < HW; p += SLIC_THREADS) lab[p] = 0;
+  if (tid < K * 5) cen[tid / 5][tid % 5] = slic_cen(ws, b, K)[tid];
+  if (tid < K * 6) sums[tid / 6][tid % 6] = 0;
   __syncthreads();
+  const int p = blockIdx.x * SLIC_THREADS + tid;
+  const bool live = p < HW;
+  int best_k = 255, y = 0, x = 0;
+  int q0 = 0, q1 = 0, q2 = 0;
+  if (live) {
+    y = p / W; x = p - y * W;
+    const short* q = f + (long)p * 4;
+    q0 = q[0]; q1 = q[1]; q2 = q[2];
+    long long best = 0x7fffffffffffffffLL;
+    for (int k = 0; k < K; ++k) {
+      const int cy = cen[k][0] >> 4, cx = cen[k][1] >> 4;                 // int(centre), centres are >= 0
+      if (y < cy - 2 * step || y > cy + 2 * step || x < cx - 2 * step || x > cx + 2 * step) continue;
+      const long long dy = 16 * y - cen[k][0], dx = 16 * x - cen[k][1];
+      const long long dl = q0 - cen[k][2], da = q1 - cen[k][3], db = q2 - cen[k][4];
+      const long long d = dy * dy + dx * dx + coef * (dl * dl + da * da + db * db);
+      if (d < best) { best = d; best_k = k; }
+    }
+    if (best_k == 255) best_k = lab[p];                                    // no window covers the pixel: keep
+    else lab[p] = (uint8_t)best_k;
+  }
+  // per-cluster sums: reduce over the lanes of the wave that share a cluster, one LDS atomic set per cluster
+  unsigned long long todo = __ballot(live);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int kk = __shfl(best_k, leader, 64);
+    const bool in = live && best_k == kk;
+    const unsigned long long grp = __ballot(in);
+    const int s0 = masked_wave_sum(16 * y, in), s1 = masked_wave_sum(16 * x, in);
+    const int s2 = masked_wave_sum(q0, in), s3 = masked_wave_sum(q1, in), s4 = masked_wave_sum(q2, in);
+    const int cnt = __popcll(grp);
+    if ((tid & 63) == leader && kk < SLIC_MAXK) {
+      atomicAdd(&sums[kk][0], s0); atomicAdd(&sums[kk][1], s1); atomicAdd(&sums[kk][2], s2);
+      atomicAdd(&sums[kk][3], s3); atomicAdd(&sums[kk][4], s4); atomicAdd(&sums[kk][5], cnt);
+    }
+    todo &= ~grp;
+  }
+  __syncthreads();
+  if (tid < K * 6 && sums[tid / 6][tid % 6] != 0)
+    atomicAdd(reinterpret_cast<unsigned long long*>(slic_sums(ws, b, K)) + tid, (unsigned long long)(long long)sums[tid / 6][tid % 6]);
+}
 
-  for (int it = 0; it < iters; ++it) {
-    if (tid < K * 6) sums[tid / 6][tid % 6] = 0;
-    if (tid == 0) changed = 0;
-    __syncthreads();
-    // all lanes of a wave take the same number of trips (wave-level reductions inside)
-    const int trips = (HW + SLIC_THREADS - 1) / SLIC_THREADS;
-    for (int t = 0; t < trips; ++t) {
-      const int p = t * SLIC_THREADS + tid;
-      const bool live = p < HW;
-      int best_k = 255, y = 0, x = 0;
-      int q0 = 0, q1 = 0, q2 = 0;
-      if (live) {
-        y = p / W; x = p - y * W;
-        const short* q = f + (long)p * 4;
-        q0 = q[0]; q1 = q[1]; q2 = q[2];
-        long long best = 0x7fffffffffffffffLL;
-        for (int k = 0; k < K; ++k) {
-          const int cy = cen[k][0] >> 4, cx = cen[k][1] >> 4;                 // int(centre), centres are >= 0
-          if (y < cy - 2 * step || y > cy + 2 * step || x < cx - 2 * step || x > cx + 2 * step) continue;
-          const long long dy = 16 * y - cen[k][0], dx = 16 * x - cen[k][1];
-          const long long dl = q0 - cen[k][2], da = q1 - cen[k][3], db = q2 - cen[k][4];
-          const long long d = dy * dy + dx * dx + coef * (dl * dl + da * da + db * db);
-          if (d < best) { best = d; best_k = k; }
-        }
-        if (best_k == 255) best_k = lab[p];                                    // no window covers the pixel: keep
-        if (best_k != lab[p]) { lab[p] = (uint8_t)best_k; changed = 1; }
-      }
-      // per-cluster sums: reduce over the lanes of the wave that share a cluster, one LDS atomic set per cluster
-      unsigned long long todo = __ballot(live);
-      while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int kk = __shfl(best_k, leader, 64);
-        const bool in = live && best_k == kk;
-        const unsigned long long grp = __ballot(in);
-        const int s0 = masked_wave_sum(16 * y, in), s1 = masked_wave_sum(16 * x, in);
-        const int s2 = masked_wave_sum(q0, in), s3 = masked_wave_sum(q1, in), s4 = masked_wave_sum(q2, in);
-        const int cnt = __popcll(grp);
-        if ((tid & 63) == leader) {
-          atomicAdd(&sums[kk][0], s0); atomicAdd(&sums[kk][1], s1); atomicAdd(&sums[kk][2], s2);
-          atomicAdd(&sums[kk][3], s3); atomicAdd(&sums[kk][4], s4); atomicAdd(&sums[kk][5], cnt);
-        }
-        todo &= ~grp;
-      }
-    }
-    __syncthreads();
-    const bool any = changed != 0;
-    if (tid < K && sums[tid][5] > 0) {
-      const int n = sums[tid][5];
+__global__ __launch_bounds__(64) void slic_update_kernel(void* ws, int K) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid >= K) return;
+  long long* sm = slic_sums(ws, b, K) + tid * 6;
+  int* cen = slic_cen(ws, b, K) + tid * 5;
+  const long long n = sm[5];
+  if (n > 0) {
 #pragma unroll
-      for (int c = 0; c < 5; ++c) cen[tid][c] = sums[tid][c] / n;              // truncation toward zero
-    }
-    __syncthreads();
-    if (!any) break;                                                           // assignment is a fixed point
+    for (int c = 0; c < 5; ++c) cen[c] = (int)(sm[c] / n);                  // truncation toward zero
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) sm[c] = 0;
+}
+
+// ---- stage 3: connected components by union-find (link the larger root under the smaller: the root of a component is
+// its smallest pixel index, whatever the order of the unions), every pixel of every image in parallel ----
+__device__ __forceinline__ int cc_find(const int* comp, int x) {
+  int r = comp[x];
+  while (r != x) { x = r; r = comp[x]; }
+  return x;
+}
+__device__ __forceinline__ void cc_union(int* comp, int a, int b) {
+  while (true) {
+    a = cc_find(comp, a);
+    b = cc_find(comp, b);
+    if (a == b) return;
+    if (a > b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(&comp[b], a);       // b was a root: hang it under a (or under something smaller still)
+    if (old == b) return;
+    b = old;                                      // somebody re-parented b meanwhile: merge that parent with a
   }
 }
 
-__global__ __launch_bounds__(SLIC_THREADS) void slic_connect_kernel(const uint8_t* __restrict__ labels, int* __restrict__ comp_ws,
-                                                                    int* __restrict__ aux_ws, long long* __restrict__ out,
-                                                                    int* __restrict__ n_regions, int H, int W, int min_size) {
-  __shared__ int changed;
+__global__ __launch_bounds__(256) void cc_init_kernel(int* __restrict__ comp, int* __restrict__ aux, int HW) {
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p < HW) { comp[(long)b * HW + p] = p; aux[(long)b * HW + p] = 0; }
+}
+
+__global__ __launch_bounds__(256) void cc_merge_kernel(const uint8_t* __restrict__ labels, int* __restrict__ comp_ws, int H, int W) {
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  const int HW = H * W;
+  if (p >= HW) return;
+  const uint8_t* lab = labels + (long)b * HW;
+  int* comp = comp_ws + (long)b * HW;
+  const int y = p / W, x = p - y * W;
+  const uint8_t l = lab[p];
+  if (x > 0 && lab[p - 1] == l) cc_union(comp, p, p - 1);
+  if (y > 0 && lab[p - W] == l) cc_union(comp, p, p - W);
+}
+
+__global__ __launch_bounds__(256) void cc_compress_kernel(int* __restrict__ comp_ws, int* __restrict__ aux_ws, int HW) {
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  int* comp = comp_ws + (long)b * HW;
+  const int r = cc_find(comp, p);
+  comp[p] = r;                                    // values only move toward the root: concurrent finds stay correct
+  atomicAdd(&aux_ws[(long)b * HW + r], 1);        // component sizes at the roots
+}
+
+// per image: roots in raster order, consecutive labels for components >= min_size, a small component takes the label
+// of an already-labelled neighbour of its first pixel (x+1, x-1, y+1, y-1; the last one found wins).  Leaves the final
+// label of every component in aux[root].
+__global__ __launch_bounds__(SLIC_THREADS) void cc_relabel_kernel(const int* __restrict__ comp_ws, int* __restrict__ aux_ws,
+                                                                  int* __restrict__ n_regions, int H, int W, int min_size) {
   __shared__ int n_roots;
-  __shared__ int root_px[SLIC_MAXC];     // unsorted roots, then sorted by pixel index
-  __shared__ int root_sorted[SLIC_MAXC];
+  __shared__ int root_px[SLIC_MAXC];     // unsorted roots
+  __shared__ int root_sorted[SLIC_MAXC]; // sorted by pixel index
   __shared__ int final_lab[SLIC_MAXC];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int HW = H * W;
-  const uint8_t* lab = labels + (long)b * HW;
-  int* comp = comp_ws + (long)b * HW;
-  int* aux = aux_ws + (long)b * HW;      // component sizes, then rank of a root
-  long long* o = out + (long)b * HW;
-  for (int p = tid; p < HW; p += SLIC_THREADS) { comp[p] = p; aux[p] = 0; }
-  __syncthreads();
-  // components: every pixel converges to the smallest pixel index of its 4-connected same-label region
-  for (int round = 0; round < 4 * (H + W); ++round) {
-    if (tid == 0) changed = 0;
-    __syncthreads();
-    for (int p = tid; p < HW; p += SLIC_THREADS) {
-      const int y = p / W, x = p - y * W;
-      const uint8_t l = lab[p];
-      int m = comp[p];
-      if (x > 0 && lab[p - 1] == l) m = min(m, comp[p - 1]);
-      if (x + 1 < W && lab[p + 1] == l) m = min(m, comp[p + 1]);
-      if (y > 0 && lab[p - W] == l) m = min(m, comp[p - W]);
-      if (y + 1 < H && lab[p + W] == l) m = min(m, comp[p + W]);
-      m = min(m, comp[m]);                      // pointer jumping (benign race: values only decrease toward the root)
-      m = min(m, comp[m]);
-      if (m < comp[p]) { comp[p] = m; changed = 1; }
-    }
-    __syncthreads();
-    if (!changed) break;
-    __syncthreads();
-  }
+  const int* comp = comp_ws + (long)b * HW;
+  int* aux = aux_ws + (long)b * HW;      // component sizes, then rank of a root, then its final label
   if (tid == 0) n_roots = 0;
   __syncthreads();
   for (int p = tid; p < HW; p += SLIC_THREADS) {
-    atomicAdd(&aux[comp[p]], 1);
     if (comp[p] == p) {
       const int s = atomicAdd(&n_roots, 1);
       if (s < SLIC_MAXC) root_px[s] = p;
     }
   }
   __syncthreads();
-  const int n = min(n_roots, SLIC_MAXC);
-  // raster order of the first pixels (rank by counting: n is small)
-  for (int i = tid; i < n; i += SLIC_THREADS) {
+  if (n_roots > SLIC_MAXC) {             // more components than the tables hold: the cluster map is the answer
+    if (tid == 0) n_regions[b] = -1;
+    return;
+  }
+  const int n = n_roots;
+  for (int i = tid; i < n; i += SLIC_THREADS) {      // rank by counting: n is small
     int r = 0;
     for (int j = 0; j < n; ++j) r += root_px[j] < root_px[i];
     root_sorted[r] = root_px[i];
@@ -214,12 +263,11 @@ __global__ __launch_bounds__(SLIC_THREADS) void slic_connect_kernel(const uint8_
   __syncthreads();
   if (tid == 0) {
     int next = 0;
-    // sizes are read before the slot is reused for the rank
     for (int r = 0; r < n; ++r) {
       const int root = root_sorted[r];
-      const int sz = aux[root];
+      const int sz = aux[root];          // sizes are read before the slot is reused for the rank
       int fl;
-      if (sz >= min_size || n_roots > SLIC_MAXC) {
+      if (sz >= min_size) {
         fl = next++;
       } else {
         int adjacent = 0;
@@ -235,13 +283,19 @@ __global__ __launch_bounds__(SLIC_THREADS) void slic_connect_kernel(const uint8_
       final_lab[r] = fl;
       aux[root] = r;
     }
-    n_regions[b] = n_roots > SLIC_MAXC ? -1 : next;
+    n_regions[b] = next;
   }
   __syncthreads();
-  for (int p = tid; p < HW; p += SLIC_THREADS) {
-    const int root = comp[p];
-    o[p] = n_roots > SLIC_MAXC ? (long long)lab[p] : (long long)final_lab[aux[root]];
-  }
+  for (int r = tid; r < n; r += SLIC_THREADS) aux[root_sorted[r]] = final_lab[r];
+}
+
+__global__ __launch_bounds__(256) void cc_output_kernel(const uint8_t* __restrict__ labels, const int* __restrict__ comp_ws,
+                                                        const int* __restrict__ aux_ws, const int* __restrict__ n_regions,
+                                                        long long* __restrict__ out, int HW) {
+  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const long o = (long)b * HW + p;
+  out[o] = n_regions[b] < 0 ? (long long)labels[o] : (long long)aux_ws[(long)b * HW + comp_ws[o]];
 }
 
 }  // namespace
@@ -257,22 +311,50 @@ extern "C" int favit_slic_features(const float* img, int16_t* feat, int32_t B, i
   return FAVIT_OK;
 }
 
+extern "C" int64_t favit_slic_cluster_workspace(int32_t K, int32_t B) {
+  if (K <= 0 || B <= 0) return 0;
+  return (int64_t)B * (int64_t)slic_ws_stride(K);   // per image and centre: 6 int64 sums + 5 int32 coordinates
+}
+
 extern "C" int favit_slic_cluster(const int16_t* feat, uint8_t* labels, const int32_t* init_yx, int32_t K, int32_t B, int32_t H,
-                                  int32_t W, int32_t step, int64_t coef, int32_t iters, void* stream) {
-  if (!feat || !labels || !init_yx || B <= 0 || H <= 0 || W <= 0 || K <= 0 || step <= 0 || coef < 0 || iters < 0)
+                                  int32_t W, int32_t step, int64_t coef, int32_t iters, void* ws, void* stream) {
+  if (!feat || !labels || !init_yx || !ws || B <= 0 || H <= 0 || W <= 0 || K <= 0 || step <= 0 || coef < 0 || iters < 0)
     return FAVIT_ERR_INVALID;
   if (K > SLIC_MAXK || (long)H * W > (1L << 26)) return FAVIT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(slic_cluster_kernel, dim3((unsigned)B), dim3(SLIC_THREADS), 0, as_stream(stream),
-                     reinterpret_cast<const short*>(feat), labels, init_yx, K, H, W, step, (long long)coef, iters);
+  if (reinterpret_cast<uintptr_t>(ws) & 7) return FAVIT_ERR_ALIGN;
+  hipStream_t st = as_stream(stream);
+  const long HW = (long)H * W;
+  if (hipMemsetAsync(labels, 0, (size_t)B * HW, st) != hipSuccess) return FAVIT_ERR_LAUNCH;
+  hipLaunchKernelGGL(slic_seed_kernel, dim3((unsigned)B), dim3(64), 0, st, reinterpret_cast<const short*>(feat), init_yx, ws, K, H, W);
   FAVIT_CHECK_LAUNCH();
+  const dim3 grid((unsigned)((HW + SLIC_THREADS - 1) / SLIC_THREADS), (unsigned)B);
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(slic_assign_kernel, grid, dim3(SLIC_THREADS), 0, st, reinterpret_cast<const short*>(feat), labels, ws, K,
+                       H, W, step, (long long)coef);
+    FAVIT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(slic_update_kernel, dim3((unsigned)B), dim3(64), 0, st, ws, K);
+    FAVIT_CHECK_LAUNCH();
+  }
   return FAVIT_OK;
 }
 
 extern "C" int favit_slic_connect(const uint8_t* labels, int32_t* ws_comp, int32_t* ws_aux, int64_t* out, int32_t* n_regions,
                                   int32_t B, int32_t H, int32_t W, int32_t min_size, void* stream) {
   if (!labels || !ws_comp || !ws_aux || !out || !n_regions || B <= 0 || H <= 0 || W <= 0 || min_size < 0) return FAVIT_ERR_INVALID;
-  hipLaunchKernelGGL(slic_connect_kernel, dim3((unsigned)B), dim3(SLIC_THREADS), 0, as_stream(stream), labels, ws_comp, ws_aux,
-                     reinterpret_cast<long long*>(out), n_regions, H, W, min_size);
+  if ((long)H * W > (1L << 30)) return FAVIT_ERR_UNSUPPORTED;
+  hipStream_t st = as_stream(stream);
+  const int HW = H * W;
+  const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(cc_init_kernel, grid, dim3(256), 0, st, ws_comp, ws_aux, HW);
+  FAVIT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cc_merge_kernel, grid, dim3(256), 0, st, labels, ws_comp, H, W);
+  FAVIT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cc_compress_kernel, grid, dim3(256), 0, st, ws_comp, ws_aux, HW);
+  FAVIT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cc_relabel_kernel, dim3((unsigned)B), dim3(SLIC_THREADS), 0, st, ws_comp, ws_aux, n_regions, H, W, min_size);
+  FAVIT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(cc_output_kernel, grid, dim3(256), 0, st, labels, ws_comp, ws_aux, n_regions,
+                     reinterpret_cast<long long*>(out), HW);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }

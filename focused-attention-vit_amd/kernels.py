@@ -498,11 +498,48 @@ def slic(images, n_segments=16, compactness=0.1, sigma=1.0, max_num_iter=10, min
     nreg = torch.empty(B, dtype=torch.int32, device=dev)
     L = _abi.lib()
     _abi.check(L.favit_slic_features(_p(images), _p(feat), B, H, W, float(sigma), _st()), "favit_slic_features")
-    _abi.check(L.favit_slic_cluster(_p(feat), _p(lab), _p(init), Kc, B, H, W, step, coef, max_num_iter, _st()),
+    cws = torch.empty(int(L.favit_slic_cluster_workspace(Kc, B)) // 8 + 1, dtype=torch.int64, device=dev)
+    _abi.check(L.favit_slic_cluster(_p(feat), _p(lab), _p(init), Kc, B, H, W, step, coef, max_num_iter, _p(cws), _st()),
                "favit_slic_cluster")
     _abi.check(L.favit_slic_connect(_p(lab), _p(ws[0]), _p(ws[1]), _p(out), _p(nreg), B, H, W, min_size, _st()),
                "favit_slic_connect")
     return (out, feat, lab.view(B, H, W), nreg) if stages else out
+
+
+def slic_stage_times(images, n_segments=16, compactness=0.1, sigma=1.0, max_num_iter=10, min_size_factor=0.5, reps=5):
+    """[(stage, ms)] of the three SLIC launches (tools/slic_bench.py)."""
+    out = []
+    import functools
+    B, _, H, W = images.shape
+    ys, xs, step = slic_grid(H, W, n_segments)
+    dev = images.device
+    init = torch.tensor([[y, x] for y in ys for x in xs], dtype=torch.int32, device=dev)
+    Kc = init.shape[0]
+    coef = int(round((step / float(compactness)) ** 2))
+    min_size = int(min_size_factor * (H * W / float(Kc)))
+    feat = torch.empty((B, H * W, 4), dtype=torch.int16, device=dev)
+    lab = torch.empty((B, H * W), dtype=torch.uint8, device=dev)
+    ws = torch.empty((2, B, H * W), dtype=torch.int32, device=dev)
+    o = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    nreg = torch.empty(B, dtype=torch.int32, device=dev)
+    L = _abi.lib()
+    cws = torch.empty(int(L.favit_slic_cluster_workspace(Kc, B)) // 8 + 1, dtype=torch.int64, device=dev)
+    stages = [
+        ("features", lambda: L.favit_slic_features(_p(images), _p(feat), B, H, W, float(sigma), _st())),
+        ("cluster", lambda: L.favit_slic_cluster(_p(feat), _p(lab), _p(init), Kc, B, H, W, step, coef, max_num_iter, _p(cws), _st())),
+        ("connect", lambda: L.favit_slic_connect(_p(lab), _p(ws[0]), _p(ws[1]), _p(o), _p(nreg), B, H, W, min_size, _st())),
+    ]
+    for name, fn in stages:
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out.append((name, e0.elapsed_time(e1) / reps))
+    return out
 
 
 def cross_entropy(logits, labels, grad_scale=None):

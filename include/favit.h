@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FAVIT_ABI_VERSION 3
+#define FAVIT_ABI_VERSION 4
 
 enum { FAVIT_F32 = 0, FAVIT_BF16 = 1, FAVIT_FP8 = 2 };
 /* OCP 8-bit float formats of gfx950 (NOT the MI300X fnuz encodings) */
@@ -222,14 +222,16 @@ int favit_image_transform(const uint8_t* src, uint8_t* tmp, float* out, uint8_t*
  * the CPU restatement oracle/slic_oracle.py.
  *   features: img fp32 [B,3,H,W] -> feat int16 [B,H*W,4] = round(16 * CIELAB(gaussian_sigma(img))), lane 3 = 0
  *   cluster : k-means, K <= 64 centres seeded at init_yx [K,2] (int32 y, x), window +-2*step, distance
- *             256*spatial^2 + coef*dq^2 (int64), `iters` rounds (early exit at a fixed point) -> labels uint8 [B,H*W]
+ *             256*spatial^2 + coef*dq^2 (int64), `iters` rounds -> labels uint8 [B,H*W]; ws: 8-byte aligned device
+ *             workspace of favit_slic_cluster_workspace(K, B) bytes (per-centre sums and coordinates)
  *   connect : 4-connected components in raster order, components < min_size merged into a labelled neighbour,
  *             consecutive labels from 0 -> out int64 [B,H*W]; n_regions int32 [B] (-1: more than 2048 components,
  *             out = the cluster map); ws_comp / ws_aux: int32 [B,H*W] workspaces.
  * ---------------------------------------------------------------------------------- */
 int favit_slic_features(const float* img, int16_t* feat, int32_t B, int32_t H, int32_t W, float sigma, void* stream);
+int64_t favit_slic_cluster_workspace(int32_t K, int32_t B);
 int favit_slic_cluster(const int16_t* feat, uint8_t* labels, const int32_t* init_yx, int32_t K, int32_t B, int32_t H,
-                       int32_t W, int32_t step, int64_t coef, int32_t iters, void* stream);
+                       int32_t W, int32_t step, int64_t coef, int32_t iters, void* ws, void* stream);
 int favit_slic_connect(const uint8_t* labels, int32_t* ws_comp, int32_t* ws_aux, int64_t* out, int32_t* n_regions,
                        int32_t B, int32_t H, int32_t W, int32_t min_size, void* stream);
 
