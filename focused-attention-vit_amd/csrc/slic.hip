@@ -140,9 +140,12 @@ __global__ __launch_bounds__(SLIC_THREADS) void slic_assign_kernel(const short* 
     for (int k = 0; k < K; ++k) {
       const int cy = cen[k][0] >> 4, cx = cen[k][1] >> 4;                 // int(centre), centres are >= 0
       if (y < cy - 2 * step || y > cy + 2 * step || x < cx - 2 * step || x > cx + 2 * step) continue;
-      const long long dy = 16 * y - cen[k][0], dx = 16 * x - cen[k][1];
-      const long long dl = q0 - cen[k][2], da = q1 - cen[k][3], db = q2 - cen[k][4];
-      const long long d = dy * dy + dx * dx + coef * (dl * dl + da * da + db * db);
+      // 32-bit differences, 32x32 -> 64-bit products (one v_mad_i64_i32 each): the same integers as 64-bit arithmetic
+      const int dy = 16 * y - cen[k][0], dx = 16 * x - cen[k][1];
+      const int dl = q0 - cen[k][2], da = q1 - cen[k][3], db = q2 - cen[k][4];
+      const long long sp = (long long)dy * dy + (long long)dx * dx;
+      const long long cq = (long long)dl * dl + (long long)da * da + (long long)db * db;
+      const long long d = sp + coef * cq;
       if (d < best) { best = d; best_k = k; }
     }
     if (best_k == 255) best_k = lab[p];                                    // no window covers the pixel: keep
