@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--no-gemm-trace", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="cfg1 / cfg3: eager launches instead of the replayed HIP graph")
     ap.add_argument("--side-stream", action="store_true", help="run weight-gradient GEMMs on a second HIP stream")
+    ap.add_argument("--bucket-mb", type=float, default=0.0, help="all-reduce bucket size in MiB (default: dp.GradSync's own choice)")
     ap.add_argument("--host-input", action="store_true",
                     help="also measure the PCIe-inclusive rate: uint8 HWC batches in pinned HOST memory -> async copy + "
                          "device transform (data.DeviceLoader) -> step; reported as `pcie_inclusive`, never as `value`")
@@ -196,8 +197,12 @@ def main():
     ndev = max(1, torch.cuda.device_count())
     dev = torch.device("cuda", local % ndev)
     torch.cuda.set_device(dev)
-    if world > 1:
+    force_dp = bool(os.environ.get("FAVIT_DP_FORCE"))          # one rank, but every collective is issued (RCCL call path)
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -222,7 +227,8 @@ def main():
         segs = torch.from_numpy(np.stack([segs_np[i % 8] for i in range(B)])).to(dev)
         model.segmentation.set_label_maps(segs)
         segs_np = np.stack([segs_np[i % 8] for i in range(max(B, c["cpu_batch"]))])
-    opt = pkg.train.FusedAdamW(pkg.train.param_groups(model, lr=1e-4), lr=1e-4, weight_decay=0.05)
+    opt = pkg.train.FusedAdamW(pkg.train.param_groups(model, lr=1e-4), lr=1e-4, weight_decay=0.05,
+                               bucket_mb=args.bucket_mb or None)
     graphed = args.config in ("cfg1", "cfg3") and not args.no_graph
     if graphed:
         # hundreds of launches of a few microseconds per step: the Python launch path, not the GPU, would set the

@@ -81,6 +81,9 @@ class GradSync:
                  group: Optional[dist.ProcessGroup] = None):
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # FAVIT_DP_FORCE=1: issue the collectives in a one-rank group too (tests/test_dp_gpu.py: the real RCCL call
+        # path -- async all-reduce of flat-buffer slices from the autograd thread -- on a one-GPU box)
+        self._active = self.world > 1 or (dist.is_initialized() and bool(os.environ.get("FAVIT_DP_FORCE")))
         self._host_staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
         if bucket_mb is None:
             bucket_mb = min(32.0, max(4.0, flat.numel * 4 / (1 << 20) / 8))
@@ -107,7 +110,7 @@ class GradSync:
         self._hooks = []
         self.defer = bool(os.environ.get("FAVIT_DP_DEFER"))     # debugging aid: launch every bucket from finish()
         self._index = {id(p): i for i, p in enumerate(flat.params)}
-        if self.world > 1:
+        if self._active:
             for i, p in enumerate(flat.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
@@ -116,7 +119,7 @@ class GradSync:
         """Called by the kernels' direct gradient-accumulation path (functional.set_grad_ready_hook)
         for parameters autograd never sees a gradient for."""
         i = self._index.get(id(p))
-        if i is not None and self.world > 1:
+        if i is not None and self._active:
             self._event(i, p, True)
 
     def no_sync(self):
@@ -171,7 +174,7 @@ class GradSync:
         self._handles = []
 
     def _launch(self, b):
-        if self._launched[b] or self.world == 1:
+        if self._launched[b] or not self._active:
             return
         s, e, _ = self.buckets[b]
         buf = self.flat.flat_g[s:e]
@@ -192,7 +195,7 @@ class GradSync:
         """Wait for every bucket (launching the ones whose hooks did not fire, e.g. frozen or
         unused parameters).  average=True turns the sums into means in place; the fused
         optimizer passes average=False and folds 1/world into its gradient scale instead."""
-        if self.world > 1:
+        if self._active:
             for b in range(len(self.buckets)):
                 self._launch(b)
             for k, (h, _) in enumerate(self._handles):

@@ -79,3 +79,56 @@ def test_dp_two_ranks_through_the_kernels(favit, tmp_path, mode, tol):
                 assert err < tol, (k, float(err))
     finally:
         favit.set_compute_dtype("fp32")
+
+
+def _nccl_worker(rank, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["FAVIT_DP_FORCE"] = "1"                      # one rank, but issue every collective
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    pkg = importlib.import_module("focused-attention-vit_amd")
+    pkg.set_compute_dtype("bf16")
+    m = _model(pkg)
+    opt = pkg.train.FusedAdamW(pkg.train.param_groups(m, lr=1e-2), lr=1e-2, weight_decay=0.0, bucket_mb=0.05)
+    n_buckets = sum(len(g["sync"].buckets) for g in opt.groups)
+    x, y = _batch()
+    xs, ys = x.cuda(), y.cuda()
+    opt.zero_grad()
+    pkg.train.cross_entropy(m(xs), ys).backward()
+    launched = [all(g["sync"]._launched) for g in opt.groups]
+    n_handles = sum(len(g["sync"]._handles) for g in opt.groups)
+    for g in opt.groups:
+        g["sync"].finish(average=False)
+    grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+    losses = [float(pkg.train.train_step(m, xs, ys, opt)) for _ in range(3)]
+    torch.cuda.synchronize()
+    torch.save({"grads": grads, "launched": launched, "n_handles": n_handles, "n_buckets": n_buckets, "losses": losses}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_call_path_single_rank(favit, tmp_path):
+    """RCCL itself (backend "nccl") on the one GPU of the box: a one-rank group in which GradSync still issues every
+    bucket's asynchronous all-reduce from the autograd thread during backward (FAVIT_DP_FORCE), waits on the handles
+    and feeds the fused AdamW.  A one-rank sum is the identity, so gradients must equal the plain single-process ones;
+    what this covers is everything around the collective that a multi-GPU run uses (library load, communicator
+    creation with device_id, stream ordering of the flat-buffer slices, handle waits, barrier)."""
+    out = str(tmp_path / "nccl.pt")
+    mp.spawn(_nccl_worker, args=(34500 + (os.getpid() % 2000), out), nprocs=1, join=True)
+    r = torch.load(out, weights_only=True)
+    assert all(r["launched"]) and r["n_handles"] == r["n_buckets"] >= 3
+    assert r["losses"][-1] < r["losses"][0]
+    favit.set_compute_dtype("bf16")
+    try:
+        m = _model(favit)
+        x, y = _batch()
+        favit.train.cross_entropy(m(x.cuda()), y.cuda()).backward()
+        for k, p in m.named_parameters():
+            ref = p.grad.detach().cpu()
+            err = (r["grads"][k] - ref).norm() / max(ref.norm().item(), 1e-12)
+            assert err < 2e-2, (k, float(err))
+    finally:
+        favit.set_compute_dtype("fp32")
