@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "favit.h")
 
 F32, BF16, FP8 = 0, 1, 2
 E4M3, E5M2 = 0, 1
-ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_SAVEGRAD, ACT_MULAUX = 0, 1, 2, 3, 4
 POOL = {"mean": 0, "max": 1, "attention": 2}
 
 vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float

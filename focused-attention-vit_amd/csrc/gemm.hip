@@ -249,6 +249,18 @@ template <typename InT> __device__ __forceinline__ float epi_gelu(float v) {
 template <typename InT> __device__ __forceinline__ float epi_dgelu(float v) {
   if constexpr (sizeof(InT) == 2) return dgelu_fast(v); else return dgelu_f(v);
 }
+// GELU and its derivative together (FAVIT_ACT_GELU_SAVEGRAD): Phi and phi share the exponential
+template <typename InT> __device__ __forceinline__ void epi_gelu_both(float v, float& h, float& g) {
+  if constexpr (sizeof(InT) == 2) {
+    float c, d;
+    gelu_terms_fast(v, c, d);
+    h = v * c;
+    g = fmaf(v, d, c);
+  } else {
+    h = gelu_f(v);
+    g = dgelu_f(v);
+  }
+}
 
 template <typename InT, typename OutT, int TBM = BM, int NT = NTHREADS>
 __device__ __forceinline__ void run_epilogue(const KParams& p, const float* epi, long m0, long n0, OutT* C,
@@ -266,19 +278,14 @@ __device__ __forceinline__ void run_epilogue(const KParams& p, const float* epi,
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
         a[0] += b.x; a[1] += b.y; a[2] += b.z; a[3] += b.w;
       }
-      if (p.aux_out) {
-        OutT* ao = reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n;
-        if constexpr (sizeof(OutT) == 4) {
-          *reinterpret_cast<float4*>(ao) = make_float4(a[0], a[1], a[2], a[3]);
-        } else {
-          bf16x4 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
-          *reinterpret_cast<bf16x4*>(ao) = o;
-        }
-      }
+      float ax[4] = {a[0], a[1], a[2], a[3]};            // what aux_out receives: the pre-activation, or GELU'
       if (p.act == FAVIT_ACT_GELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[j] = epi_gelu<InT>(a[j]);
-      } else if (p.act == FAVIT_ACT_DGELU) {
+      } else if (p.act == FAVIT_ACT_GELU_SAVEGRAD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi_gelu_both<InT>(a[j], a[j], ax[j]);
+      } else if (p.act == FAVIT_ACT_DGELU || p.act == FAVIT_ACT_MULAUX) {
         const InT* ai = reinterpret_cast<const InT*>(p.aux_in) + m * p.ld_aux_in + n;
         float x[4];
         if constexpr (sizeof(InT) == 4) {
@@ -289,7 +296,16 @@ __device__ __forceinline__ void run_epilogue(const KParams& p, const float* epi,
           x[0] = (float)t[0]; x[1] = (float)t[1]; x[2] = (float)t[2]; x[3] = (float)t[3];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) a[j] *= epi_dgelu<InT>(x[j]);
+        for (int j = 0; j < 4; ++j) a[j] *= (p.act == FAVIT_ACT_MULAUX) ? x[j] : epi_dgelu<InT>(x[j]);
+      }
+      if (p.aux_out) {
+        OutT* ao = reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n;
+        if constexpr (sizeof(OutT) == 4) {
+          *reinterpret_cast<float4*>(ao) = make_float4(ax[0], ax[1], ax[2], ax[3]);
+        } else {
+          bf16x4 o = {(bf16_t)ax[0], (bf16_t)ax[1], (bf16_t)ax[2], (bf16_t)ax[3]};
+          *reinterpret_cast<bf16x4*>(ao) = o;
+        }
       }
       if (p.drop_thresh) {
 #pragma unroll
@@ -319,10 +335,14 @@ __device__ __forceinline__ void run_epilogue(const KParams& p, const float* epi,
       if (m >= p.M || n >= p.N) continue;
       float v = epi[epi_off(row, col)] * p.alpha;
       if (first_split && p.bias) v += p.bias[n];
-      if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n] = from_f32<OutT>(v);
+      float vx = v;
       if (p.act == FAVIT_ACT_GELU) v = epi_gelu<InT>(v);
+      else if (p.act == FAVIT_ACT_GELU_SAVEGRAD) epi_gelu_both<InT>(v, v, vx);
       else if (p.act == FAVIT_ACT_DGELU)
         v *= epi_dgelu<InT>(to_f32(reinterpret_cast<const InT*>(p.aux_in)[m * p.ld_aux_in + n]));
+      else if (p.act == FAVIT_ACT_MULAUX)
+        v *= to_f32(reinterpret_cast<const InT*>(p.aux_in)[m * p.ld_aux_in + n]);
+      if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n] = from_f32<OutT>(vx);
       if (p.drop_thresh) v = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n), p.drop_thresh) ? v * p.drop_scale : 0.f;
       if (first_split && p.residual) v += p.residual[m * p.ld_res + n];
       if (p.atomic) {
@@ -694,6 +714,9 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
     for (int ii = 0; ii < NI; ++ii)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
+#ifdef FAVIT_PROBE
+        if (!(p.dbg & 0x1000))                                       // dbg 0x1000: no accumulator writes to the LDS scratch
+#endif
         *reinterpret_cast<f32x4*>(wl + (ii * 16 + (lane & 15)) * WEPI_LD + j * 16 + 4 * (lane >> 4)) = acc[Q + ii][CB * 4 + j];
     // (same wave wrote and reads: the compiler's lgkmcnt wait orders them; no barrier needed)
     bool done = false;
@@ -739,7 +762,7 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
           if constexpr (sizeof(OutT) == 4) {               // (bf16 outputs with a residual are rare: loaded in place below)
             if (p.residual) res[it & 1][c4] = *reinterpret_cast<const f32x4*>(p.residual + m * p.ld_res + n + 4 * c4);
           }
-          if (p.act == FAVIT_ACT_DGELU)
+          if (p.act == FAVIT_ACT_DGELU || p.act == FAVIT_ACT_MULAUX)
             aux[it & 1][c4] = *reinterpret_cast<const aux4_t*>(reinterpret_cast<const InT*>(p.aux_in) + m * p.ld_aux_in + n + 4 * c4);
         }
       };
@@ -757,19 +780,29 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
           a[4 * c4 + 2] = fmaf(t[2], alpha, bv[c4].z); a[4 * c4 + 3] = fmaf(t[3], alpha, bv[c4].w);
         }
         if (m >= p.M) continue;
-        auto store_vec = [&](OutT* dst) {
+        auto store_vec = [&](OutT* dst, const float (&sv)[CPL]) {
           uint4 raw;
           if constexpr (sizeof(OutT) == 4) {
-            raw = make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3]));
+            raw = make_uint4(__float_as_uint(sv[0]), __float_as_uint(sv[1]), __float_as_uint(sv[2]), __float_as_uint(sv[3]));
           } else {
             bf16x8 o;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) o[c] = (bf16_t)a[c];
+            for (int c = 0; c < 8; ++c) o[c] = (bf16_t)sv[c];
             raw = __builtin_bit_cast(uint4, o);
           }
+#ifdef FAVIT_PROBE
+          if ((p.dbg & 0x800) && raw.x != 0x12345678u) return;       // dbg 0x800: everything but the global stores (timing only)
+#endif
           store16_policy(dst, raw, p.store_policy);
         };
-        if (p.aux_out) store_vec(reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n);
+        if (p.act == FAVIT_ACT_GELU_SAVEGRAD) {
+          float gd[CPL];
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) epi_gelu_both<InT>(a[c], a[c], gd[c]);
+          if (p.aux_out) store_vec(reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n, gd);
+        } else if (p.aux_out) {
+          store_vec(reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n, a);
+        }
         if (p.act == FAVIT_ACT_GELU) {
 #pragma unroll
           for (int c = 0; c < CPL; ++c) a[c] = epi_gelu<InT>(a[c]);
@@ -778,6 +811,11 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
           for (int c4 = 0; c4 < CPL / 4; ++c4)
 #pragma unroll
             for (int c = 0; c < 4; ++c) a[4 * c4 + c] *= epi_dgelu<InT>((float)aux[it & 1][c4][c]);
+        } else if (p.act == FAVIT_ACT_MULAUX) {
+#pragma unroll
+          for (int c4 = 0; c4 < CPL / 4; ++c4)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[4 * c4 + c] *= (float)aux[it & 1][c4][c];
         }
         if (p.drop_thresh) {
 #pragma unroll
@@ -793,7 +831,7 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
             a[4 * c4] += r[0]; a[4 * c4 + 1] += r[1]; a[4 * c4 + 2] += r[2]; a[4 * c4 + 3] += r[3];
           }
         }
-        store_vec(C + m * p.ldc + n);
+        store_vec(C + m * p.ldc + n, a);
       }
     } else {
 #pragma unroll
@@ -806,10 +844,14 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
           if (n + c >= p.N) continue;
           float v = wl[row * WEPI_LD + lc + c] * alpha;
           if (p.bias) v += p.bias[n + c];
-          if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n + c] = from_f32<OutT>(v);
+          float vx = v;
           if (p.act == FAVIT_ACT_GELU) v = epi_gelu<InT>(v);
+          else if (p.act == FAVIT_ACT_GELU_SAVEGRAD) epi_gelu_both<InT>(v, v, vx);
           else if (p.act == FAVIT_ACT_DGELU)
             v *= epi_dgelu<InT>(to_f32(reinterpret_cast<const InT*>(p.aux_in)[m * p.ld_aux_in + n + c]));
+          else if (p.act == FAVIT_ACT_MULAUX)
+            v *= to_f32(reinterpret_cast<const InT*>(p.aux_in)[m * p.ld_aux_in + n + c]);
+          if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n + c] = from_f32<OutT>(vx);
           if (p.drop_thresh) v = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n + c), p.drop_thresh) ? v * p.drop_scale : 0.f;
           if (p.residual) v += p.residual[m * p.ld_res + n + c];
           C[m * p.ldc + n + c] = from_f32<OutT>(v);
@@ -1870,7 +1912,9 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
     if (!aligned(g->A, 16) || !aligned(g->B, 16) || (g->lda % 16) != 0 || (g->ldb % 16) != 0) return FAVIT_ERR_ALIGN;
   }
   if (g->in_dtype == FAVIT_F32 && g->out_dtype != FAVIT_F32) return FAVIT_ERR_UNSUPPORTED;
-  if (g->act == FAVIT_ACT_DGELU && !g->aux_in) return FAVIT_ERR_INVALID;
+  if (g->act < FAVIT_ACT_NONE || g->act > FAVIT_ACT_MULAUX) return FAVIT_ERR_INVALID;
+  if ((g->act == FAVIT_ACT_DGELU || g->act == FAVIT_ACT_MULAUX) && !g->aux_in) return FAVIT_ERR_INVALID;
+  if (g->act == FAVIT_ACT_GELU_SAVEGRAD && !g->aux_out) return FAVIT_ERR_INVALID;
   if (g->a_rowsum && g->a_kmajor) return FAVIT_ERR_UNSUPPORTED;
   const int batch = g->batch > 0 ? g->batch : 1;
   const int batch_inner = g->batch_inner > 0 ? g->batch_inner : 1;

@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import kernels as K
-from ._abi import ACT_DGELU, ACT_GELU, ACT_NONE
+from ._abi import ACT_DGELU, ACT_GELU, ACT_GELU_SAVEGRAD, ACT_MULAUX, ACT_NONE
 
 # ------------------------------------------------------------------------------------
 # configuration
@@ -314,10 +314,11 @@ def lin_fwd(a, w_c, bias, M, N, Kd, out_dtype, *, act=ACT_NONE, residual=None, w
     return (out, pre) if want_pre else out
 
 
-def lin_bwd_x(dy, w_c, M, N, Kd, out_dtype, *, dgelu_pre=None, drop=(0.0, 0), allow_fp8=True):
-    """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(pre) * dropout-mask)."""
+def lin_bwd_x(dy, w_c, M, N, Kd, out_dtype, *, dgelu_pre=None, pre_is_grad=False, drop=(0.0, 0), allow_fp8=True):
+    """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(pre) * dropout-mask; pre_is_grad: `dgelu_pre` already holds
+    gelu'(pre), saved by the forward's ACT_GELU_SAVEGRAD epilogue)."""
     dx = torch.empty((M, Kd), dtype=out_dtype, device=dy.device)
-    act = ACT_DGELU if dgelu_pre is not None else ACT_NONE
+    act = (ACT_MULAUX if pre_is_grad else ACT_DGELU) if dgelu_pre is not None else ACT_NONE
     if _use_fp8(allow_fp8, dy, w_c, k_dims=(N,)) and (dgelu_pre is None or dgelu_pre.dtype == torch.bfloat16):
         dyq, _, sdy, _ = _q8(dy, E5M2)
         _, wqt, sw, _ = _q8(w_c, E4M3)                  # [Kd, N]: W^T, k-major over N
@@ -622,17 +623,22 @@ class MLPChain:
         s1 = _seed() if p > 0 else 0
         s2 = _seed() if p > 0 else 0
         w1_c, w2_c = wcast(w1), wcast(w2)
-        h, pre = lin_fwd(xn, w1_c, b1.detach(), M, Hd, D, xn.dtype, act=ACT_GELU, want_pre=True, drop=(p, s1))
+        # Low-precision path: the fc1 epilogue saves GELU'(u) (Phi and phi share one exponential) instead of u, so the
+        # backward epilogue is a multiply: the GELU arithmetic (~20 VALU slots per element) runs once instead of twice
+        # (measured: -0.09 ms per cfg2 step; both epilogues stay bound by their 310 MB of HBM traffic).  The fp32 parity mode keeps the pre-activation and the exact erf.
+        sg = xn.dtype != torch.float32
+        h, pre = lin_fwd(xn, w1_c, b1.detach(), M, Hd, D, xn.dtype, act=ACT_GELU_SAVEGRAD if sg else ACT_GELU,
+                         want_pre=True, drop=(p, s1))
         y = lin_fwd(h, w2_c, b2.detach(), M, Do, Hd, torch.float32, residual=residual, drop=(p, s2))
-        return y, (xn, pre, h, w1_c, w2_c, p, s1, s2, prm)
+        return y, (xn, (pre, sg), h, w1_c, w2_c, p, s1, s2, prm)
 
     def bwd(self, saved, dy_lp):
-        xn, pre, h, w1_c, w2_c, p, s1, s2, prm = saved
+        xn, (pre, sg), h, w1_c, w2_c, p, s1, s2, prm = saved
         w1, b1, w2, b2 = prm
         M, D = xn.shape
         Hd, Do = w1_c.shape[0], w2_c.shape[0]
         dym = K.dropout(dy_lp, p, s2) if p > 0 else dy_lp
-        dpre = lin_bwd_x(dym, w2_c, M, Do, Hd, xn.dtype, dgelu_pre=pre, drop=(p, s1))
+        dpre = lin_bwd_x(dym, w2_c, M, Do, Hd, xn.dtype, dgelu_pre=pre, pre_is_grad=sg, drop=(p, s1))
         dw2, db2 = lin_bwd_w(dym, h, M, Do, Hd, wp=w2, bp=b2)
         dxn = lin_bwd_x(dpre, w1_c, M, Hd, D, xn.dtype)
         dw1, db1 = lin_bwd_w(dpre, xn, M, Hd, D, wp=w1, bp=b1)

@@ -42,7 +42,13 @@ enum {
   FAVIT_ERR_LAUNCH = -4       /* hipLaunchKernel reported an error */
 };
 
-enum { FAVIT_ACT_NONE = 0, FAVIT_ACT_GELU = 1, FAVIT_ACT_DGELU = 2 };
+enum {
+  FAVIT_ACT_NONE = 0,
+  FAVIT_ACT_GELU = 1,           /* out = GELU(v); aux_out (optional) receives the pre-activation v                   */
+  FAVIT_ACT_DGELU = 2,          /* out = v * GELU'(aux_in)            (aux_in = the saved pre-activation)            */
+  FAVIT_ACT_GELU_SAVEGRAD = 3,  /* out = GELU(v); aux_out (required) receives GELU'(v) instead of v                  */
+  FAVIT_ACT_MULAUX = 4          /* out = v * aux_in                   (aux_in = the saved GELU' of mode 3)           */
+};
 enum { FAVIT_POOL_MEAN = 0, FAVIT_POOL_MAX = 1, FAVIT_POOL_ATTENTION = 2 };
 
 int favit_abi_version(void);

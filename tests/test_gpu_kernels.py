@@ -580,6 +580,37 @@ def test_gemm_ping_pong_kernel(K, bk, M, N, Kd, forced, out_dtype, epi, monkeypa
     assert rel_l2(out.float(), ref) < (1e-2 if out_dtype == torch.bfloat16 else 2e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,Kd", [(300, 200, 96), (1000, 256, 128), (21760 + 37, 384, 64), (50432, 1536, 384)])
+def test_gemm_gelu_savegrad_and_mulaux_epilogues(K, dtype, M, N, Kd):
+    """ACT_GELU_SAVEGRAD (out = GELU(v), aux_out = GELU'(v)) and ACT_MULAUX (out = v * aux_in): the pair the bf16 MLP
+    chain uses so that the GELU arithmetic runs once; every epilogue implementation (128x128 vector / scalar, 256x128
+    wave-private vector / scalar, quarter-tile tail) against torch's erf GELU and its autograd derivative."""
+    A = _abi()
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    a = _rand((M, Kd), dtype, g)
+    w = _rand((N, Kd), dtype, g)
+    bias = _rand((N,), torch.float32, g)
+    out = torch.empty((M, N), dtype=dtype, device=DEV)
+    gd = torch.empty((M, N), dtype=dtype, device=DEV)
+    K.gemm(a, w, out, M, N, Kd, Kd, Kd, N, bias=bias, act=A.ACT_GELU_SAVEGRAD, aux_out=gd, ld_aux_out=N)
+    u = (a.float() @ w.float().t() + bias).requires_grad_(True)
+    h = torch.nn.functional.gelu(u)
+    h.sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(out.float(), h.detach()) < tol
+    assert rel_l2(gd.float(), u.grad) < tol
+    # backward partner: dU = (dY . W2) * saved GELU'
+    dy = _rand((M, Kd), dtype, g)
+    w2 = _rand((Kd, N), dtype, g)                      # mn-major B: the input-gradient layout
+    du = torch.empty((M, N), dtype=dtype, device=DEV)
+    K.gemm(dy, w2, du, M, N, Kd, Kd, N, N, b_kmajor=False, act=A.ACT_MULAUX, aux_in=gd, ld_aux_in=N)
+    ref = (dy.float() @ w2.float()) * gd.float()
+    assert rel_l2(du.float(), ref) < tol
+    with pytest.raises(Exception):                     # SAVEGRAD without a destination for the derivative
+        K.gemm(a, w, out, M, N, Kd, Kd, Kd, N, act=A.ACT_GELU_SAVEGRAD)
+
+
 @pytest.mark.parametrize("bk", [True, False])
 @pytest.mark.parametrize("M,N,Kd", [(50432, 384, 384), (50432 + 100, 384, 1536), (45000 - 8, 1152, 128), (131072 + 64 * 3 + 5, 200, 64)])
 @pytest.mark.parametrize("out_dtype,epi", [(torch.bfloat16, "gelu"), (torch.bfloat16, "dgelu"), (torch.float32, "res")])
