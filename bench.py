@@ -81,20 +81,21 @@ CONFIGS = {
 }
 
 
-def build_model(pkg, cfg, dev):
+def build_model(pkg, cfg, dev, dropout=0.0):
     M = pkg.models
+    d = float(dropout)
     if cfg == "cfg1":
         return M.vit.VisionTransformer(img_size=32, patch_size=4, num_classes=10, embed_dim=192, depth=12, num_heads=3).to(dev)
     if cfg == "cfg2":
         return M.vit_mhla.VisionTransformerMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12,
-                                                num_heads=6, window_size=7, use_mhla=True, dropout=0.0,
-                                                attn_dropout=0.0, embed_dropout=0.0).to(dev)
+                                                num_heads=6, window_size=7, use_mhla=True, dropout=d,
+                                                attn_dropout=d, embed_dropout=d).to(dev)
     if cfg == "cfg3":
         return M.sppp_mhla.SPPPViTMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12, num_heads=6,
                                        num_superpixels=16, pooling_type="mean", window_size=7, use_mhla=True).to(dev)
     return M.vit_mhla.VisionTransformerMHLA(img_size=384, patch_size=16, num_classes=1000, embed_dim=768, depth=12,
-                                            num_heads=12, window_size=7, use_mhla=True, dropout=0.0, attn_dropout=0.0,
-                                            embed_dropout=0.0).to(dev)
+                                            num_heads=12, window_size=7, use_mhla=True, dropout=d, attn_dropout=d,
+                                            embed_dropout=d).to(dev)
 
 
 def host_cores():
@@ -183,6 +184,9 @@ def main():
     ap.add_argument("--no-gemm-trace", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="cfg1 / cfg3: eager launches instead of the replayed HIP graph")
     ap.add_argument("--side-stream", action="store_true", help="run weight-gradient GEMMs on a second HIP stream")
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="dropout = attn_dropout = embed_dropout of the cfg2 / cfg4 models (the reference's main.py:106 "
+                         "trains with 0.1; the headline row is 0.0, SURVEY 8d)")
     ap.add_argument("--bucket-mb", type=float, default=0.0, help="all-reduce bucket size in MiB (default: dp.GradSync's own choice)")
     ap.add_argument("--host-input", action="store_true",
                     help="also measure the PCIe-inclusive rate: uint8 HWC batches in pinned HOST memory -> async copy + "
@@ -215,7 +219,7 @@ def main():
     pkg.set_side_stream(args.side_stream)
 
     torch.manual_seed(1234)
-    model = build_model(pkg, args.config, dev)
+    model = build_model(pkg, args.config, dev, args.dropout)
     model.train()
     B = args.batch or c["batch"]
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -321,7 +325,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{c['name']}, {B} images/GPU; step = fwd + cross-entropy + bwd + grad all-reduce + AdamW",
                        "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random-init (seed 1234)",
-                       "baseline_config": args.config, "hip_graph": bool(graphed)},
+                       "baseline_config": args.config, "hip_graph": bool(graphed), "dropout": args.dropout},
             "gpu_ms_per_step_events": round(e_begin.elapsed_time(e_end) / args.steps, 3),
             "loss": round(loss_val, 5),
             "model_tflops_per_s": round(n_img * flops_per_image_train(**c["flops"]) / dt / 1e12, 2),

@@ -82,14 +82,22 @@ __device__ __forceinline__ float dgelu_fast(float x) {
   return fmaf(x, p, c);
 }
 
-// Counter-based RNG for dropout: one 32-bit draw per (seed, index); the same draw is
-// recomputed in backward, so no mask is stored.  (splitmix64 finaliser)
+// Counter-based RNG for dropout: one 32-bit draw per (seed, index); the same draw is recomputed in backward, so no
+// mask is stored.  32-bit arithmetic throughout (the splitmix64 finaliser used before cost ~28 VALU operations per
+// element -- two 64-bit multiplies -- and made every dropout epilogue VALU-bound): an affine map of the index whose
+// odd multiplier and offset come from the seed (masks of different seeds are not shifted copies of each other),
+// then a 32-bit multiply-xorshift finaliser (the "lowbias32" constants): for a fixed seed the draws of 2^32
+// consecutive indices are a permutation of the 32-bit values.  tests/test_gpu_kernels.py checks keep rates and the
+// absence of correlation across lags, strides and seeds.
 __device__ __forceinline__ uint32_t favit_rand_u32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  const uint32_t k1 = ((uint32_t)seed * 0x9E3779B1u) | 1u, k2 = (uint32_t)(seed >> 32) * 0x85EBCA77u;
+  uint32_t x = (uint32_t)idx * k1 + k2 + (uint32_t)(idx >> 32) * 0xC2B2AE3Du;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
 }
 // keep with probability 1-p
 __device__ __forceinline__ bool favit_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {

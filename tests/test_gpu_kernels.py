@@ -103,6 +103,33 @@ def test_gemm_batched_strided(K, dtype):
     assert rel_l2(S, ref) < 2e-5
 
 
+def test_dropout_draws_are_uniform_and_independent_across_seeds(K):
+    """The counter-based dropout draws (common.h favit_rand_u32: affine index map keyed by the seed + 32-bit
+    finaliser): keep rate, no correlation between neighbouring elements, between strided elements, between the masks of
+    different seeds (consecutive, random, and seeds that differ only in the high word), and no shifted copies."""
+    n = 1 << 22
+    ones = torch.ones(n, device=DEV)
+    def mask(seed, p=0.25):
+        return (K.dropout(ones, p, seed) != 0).float()
+    seeds = [1, 2, 3, 0x123456789ABCDEF, 0x123456789ABCDEF + (1 << 32), 0x7FFFFFFF00000000, 0x42]
+    ms = [mask(s) for s in seeds]
+    tol = 5.0 / (n ** 0.5)                                   # five sigma of a Bernoulli mean / correlation estimate
+    for m in ms:
+        assert abs(float(m.mean()) - 0.75) < tol
+        c = m - 0.75
+        for lag in (1, 2, 3, 64, 384, 1536, 4096):
+            assert abs(float((c[:-lag] * c[lag:]).mean()) / 0.1875) < tol, lag
+    for i in range(len(ms)):
+        for j in range(i + 1, len(ms)):
+            ci, cj = ms[i] - 0.75, ms[j] - 0.75
+            assert abs(float((ci * cj).mean()) / 0.1875) < tol, (seeds[i], seeds[j])
+            for sh in (1, 7, 4097):                          # not a shifted copy either way
+                assert abs(float((ci[sh:] * cj[:-sh]).mean()) / 0.1875) < tol
+                assert abs(float((ci[:-sh] * cj[sh:]).mean()) / 0.1875) < tol
+    for p in (0.1, 0.5, 0.9):
+        assert abs(float(mask(99, p).mean()) - (1 - p)) < tol
+
+
 def test_gemm_dropout_epilogue_matches_dropout_kernel(K):
     g = torch.Generator(device=DEV).manual_seed(13)
     M, N, Kd = 256, 128, 64
