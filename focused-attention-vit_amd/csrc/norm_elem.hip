@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy,
                                                      const float* __restrict__ dres, float* __restrict__ dx,
                                                      long lddx, LpT* __restrict__ dx_lp,
                                                      float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
-                                                     long rows, int D) {
+                                                     long rows, int D, uint32_t lp_thresh, float lp_scale,
+                                                     uint64_t lp_seed) {
   __shared__ float red[4][2][256 * NV > 2048 ? 2048 : 256 * NV];   // [wave][gamma|beta][D padded]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D >> 2;
@@ -130,7 +131,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy,
           o0 += r.x; o1 += r.y; o2 += r.z; o3 += r.w;
         }
         *reinterpret_cast<float4*>(dx + row * lddx + 4 * i4) = make_float4(o0, o1, o2, o3);
-        if (dx_lp) store4<LpT>(dx_lp + row * (long)D + 4 * i4, o0, o1, o2, o3);
+        if (dx_lp) {
+          if (lp_thresh) {       // the low-precision copy only feeds a branch whose OUTPUT was dropped: apply that mask here
+            const uint64_t e = (uint64_t)(row * (long)D + 4 * i4);
+            o0 = favit_keep(lp_seed, e, lp_thresh) ? o0 * lp_scale : 0.f;
+            o1 = favit_keep(lp_seed, e + 1, lp_thresh) ? o1 * lp_scale : 0.f;
+            o2 = favit_keep(lp_seed, e + 2, lp_thresh) ? o2 * lp_scale : 0.f;
+            o3 = favit_keep(lp_seed, e + 3, lp_thresh) ? o3 * lp_scale : 0.f;
+          }
+          store4<LpT>(dx_lp + row * (long)D + 4 * i4, o0, o1, o2, o3);
+        }
       }
     }
   }
@@ -427,24 +437,27 @@ extern "C" int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x,
                                    const float* mean, const float* rstd, const float* dres, float* dx, int64_t lddx,
                                    void* dx_lp, int lp_dtype, float* dgamma_part, float* dbeta_part, int32_t nparts,
                                    float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t D,
-                                   void* stream) {
+                                   float lp_dropout_p, uint64_t lp_dropout_seed, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_part || !dbeta_part || rows <= 0 || D <= 0 ||
       nparts <= 0)
     return FAVIT_ERR_INVALID;
   if (dbeta_part != dgamma_part + (long)nparts * D) return FAVIT_ERR_INVALID;   // [2][nparts][D] workspace
   if ((D & 3) || (ldx & 3) || (lddx & 3)) return FAVIT_ERR_ALIGN;
   if (dy_dtype != lp_dtype && dx_lp) return FAVIT_ERR_UNSUPPORTED;
+  if (lp_dropout_p < 0.f || lp_dropout_p >= 1.f) return FAVIT_ERR_INVALID;
+  const uint32_t lp_thresh = dx_lp ? dropout_threshold(lp_dropout_p) : 0u;
+  const float lp_scale = 1.0f / (1.0f - lp_dropout_p);
   hipStream_t st = as_stream(stream);
   const dim3 grid((unsigned)nparts);
 #define LN_BWD(NV)                                                                                                 \
   if (dy_dtype == FAVIT_F32)                                                                                       \
     hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, dim3(256), 0, st, (const float*)dy, x, (long)ldx,  \
                        gamma, mean, rstd, dres, dx, (long)lddx, (float*)dx_lp, dgamma_part, dbeta_part, (long)rows, \
-                       D);                                                                                         \
+                       D, lp_thresh, lp_scale, lp_dropout_seed);                                                                                    \
   else                                                                                                             \
     hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t, NV>), grid, dim3(256), 0, st, (const bf16_t*)dy, x,          \
                        (long)ldx, gamma, mean, rstd, dres, dx, (long)lddx, (bf16_t*)dx_lp, dgamma_part,            \
-                       dbeta_part, (long)rows, D)
+                       dbeta_part, (long)rows, D, lp_thresh, lp_scale, lp_dropout_seed)
   LN_DISPATCH_NV(D, LN_BWD);
 #undef LN_BWD
   FAVIT_CHECK_LAUNCH();

@@ -483,12 +483,17 @@ class MHLAChain:
         y = lin_fwd(o, wp_c, bp.detach(), M, D, D, torch.float32, residual=residual, drop=(pp, sp))
         return y, (xn, weff, qkv, o, wp_c, mask, B, L, pa, sa, pp, sp, prm)
 
-    def bwd(self, saved, dy_lp):
+    @staticmethod
+    def out_dropout(saved):
+        """(p, seed) of the dropout on this branch's output (the mask its incoming gradient must carry)."""
+        return saved[10], saved[11]
+
+    def bwd(self, saved, dy_lp, premasked=False):
         xn, weff, qkv, o, wp_c, mask, B, L, pa, sa, pp, sp, prm = saved
         wqkv, bqkv, wl, bl, wp, bp = prm
         M, D = xn.shape
         H, hd = self.H, D // self.H
-        dym = K.dropout(dy_lp, pp, sp) if pp > 0 else dy_lp
+        dym = K.dropout(dy_lp, pp, sp) if (pp > 0 and not premasked) else dy_lp
         do = lin_bwd_x(dym, wp_c, M, D, D, xn.dtype)
         dwp, dbp = lin_bwd_w(dym, o, M, D, D, wp=wp, bp=bp)
         dqkv = K.mhla_attn_bwd(qkv, do, B, L, H, hd, self.W, mask, pa, sa)
@@ -537,12 +542,16 @@ class DenseChain:
         y = lin_fwd(o, wp_c, bp.detach(), M, D, D, torch.float32, residual=residual, drop=(pp, sp))
         return y, (xn, wqkv_c, qkv, o, wp_c, att, mask, B, L, pa, sa, pp, sp, prm)
 
-    def bwd(self, saved, dy_lp):
+    @staticmethod
+    def out_dropout(saved):
+        return saved[11], saved[12]
+
+    def bwd(self, saved, dy_lp, premasked=False):
         xn, wqkv_c, qkv, o, wp_c, att, mask, B, L, pa, sa, pp, sp, prm = saved
         wqkv, bqkv, wp, bp = prm
         M, D = xn.shape
         H, hd = self.H, D // self.H
-        dym = K.dropout(dy_lp, pp, sp) if pp > 0 else dy_lp
+        dym = K.dropout(dy_lp, pp, sp) if (pp > 0 and not premasked) else dy_lp
         do = lin_bwd_x(dym, wp_c, M, D, D, xn.dtype)
         dwp, dbp = lin_bwd_w(dym, o, M, D, D, wp=wp, bp=bp)
         dqkv = torch.empty_like(qkv)
@@ -632,12 +641,16 @@ class MLPChain:
         y = lin_fwd(h, w2_c, b2.detach(), M, Do, Hd, torch.float32, residual=residual, drop=(p, s2))
         return y, (xn, (pre, sg), h, w1_c, w2_c, p, s1, s2, prm)
 
-    def bwd(self, saved, dy_lp):
+    @staticmethod
+    def out_dropout(saved):
+        return saved[5], saved[7]
+
+    def bwd(self, saved, dy_lp, premasked=False):
         xn, (pre, sg), h, w1_c, w2_c, p, s1, s2, prm = saved
         w1, b1, w2, b2 = prm
         M, D = xn.shape
         Hd, Do = w1_c.shape[0], w2_c.shape[0]
-        dym = K.dropout(dy_lp, p, s2) if p > 0 else dy_lp
+        dym = K.dropout(dy_lp, p, s2) if (p > 0 and not premasked) else dy_lp
         dpre = lin_bwd_x(dym, w2_c, M, Do, Hd, xn.dtype, dgelu_pre=pre, pre_is_grad=sg, drop=(p, s1))
         dw2, db2 = lin_bwd_w(dym, h, M, Do, Hd, wp=w2, bp=b2)
         dxn = lin_bwd_x(dpre, w1_c, M, Hd, D, xn.dtype)
@@ -812,16 +825,28 @@ class EncoderOp:
         grads = []
         begin_wgrads()
         try:
-            for bs, tp in zip(reversed(self.blocks), reversed(tapes)):
+            # The low-precision copy of the stream gradient only feeds the next branch's backward GEMMs; when that
+            # branch's output was dropped in forward, the LayerNorm backward that produces the copy applies the mask
+            # (no separate masking pass: 24 launches of 28 us per cfg2 step at dropout 0.1).
+            order = list(zip(reversed(self.blocks), reversed(tapes)))
+            premasked = False
+            for bi, (bs, tp) in enumerate(order):
                 x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm = tp
-                dxn2, gm = bs.mlp.bwd(sm, g_lp)
+                dxn2, gm = bs.mlp.bwd(sm, g_lp, premasked=premasked)
+                pd = bs.attn.out_dropout(sa) if hasattr(bs.attn, "out_dropout") else (0.0, 0)
                 g, g_lp, dg2, db2 = K.layernorm_bwd(dxn2, x1, D, g2, mu2, rs2, M, D, dres=g, want_lp=True,
-                                                    dg_out=_gt(g2), db_out=_gt(b2))
+                                                    dg_out=_gt(g2), db_out=_gt(b2), lp_drop=pd)
                 if dg2 is None:
                     _ready(g2, b2)
-                dxn1, ga = bs.attn.bwd(sa, g_lp)
+                dxn1, ga = (bs.attn.bwd(sa, g_lp, premasked=pd[0] > 0) if hasattr(bs.attn, "out_dropout")
+                            else bs.attn.bwd(sa, g_lp))
+                pd = (0.0, 0)
+                if bi + 1 < len(order):
+                    nbs, ntp = order[bi + 1]
+                    pd = nbs.mlp.out_dropout(ntp[9])
+                premasked = pd[0] > 0
                 g, g_lp, dg1, db1 = K.layernorm_bwd(dxn1, x, D, g1, mu1, rs1, M, D, dres=g, want_lp=True,
-                                                    dg_out=_gt(g1), db_out=_gt(b1))
+                                                    dg_out=_gt(g1), db_out=_gt(b1), lp_drop=pd)
                 if dg1 is None:
                     _ready(g1, b1)
                 flush_wgrads()

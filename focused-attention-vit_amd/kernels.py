@@ -217,10 +217,11 @@ def layernorm_fwd(x, ldx, gamma, beta, rows, D, out_dtype, eps=1e-5):
 
 
 def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None, lddx=None, want_lp=False,
-                  dg_out=None, db_out=None):
+                  dg_out=None, db_out=None, lp_drop=(0.0, 0)):
     """Returns dx (fp32, row stride lddx), dx_lp (dy.dtype copy or None), dgamma, dbeta.
     dg_out / db_out: optional fp32 [D] gradient buffers the affine gradients are ACCUMULATED into
-    (then None is returned in their place)."""
+    (then None is returned in their place).  lp_drop = (p, seed): dx_lp carries that dropout mask (the branch it
+    feeds had its output dropped in forward), saving a separate masking pass."""
     require_gpu(dy, x)
     dev = x.device
     if dx is None:
@@ -237,7 +238,8 @@ def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None,
         dg, db = dgb[0], dgb[1]
     _abi.check(_abi.lib().favit_layernorm_bwd(_p(dy), dt(dy), _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres),
                                               _p(dx), lddx, _p(dx_lp), dt(dy), _p(part[0]), _p(part[1]), nparts,
-                                              _p(dg), _p(db), int(acc), rows, D, _st()), "favit_layernorm_bwd")
+                                              _p(dg), _p(db), int(acc), rows, D, float(lp_drop[0]), int(lp_drop[1]) & ((1 << 64) - 1),
+                                              _st()), "favit_layernorm_bwd")
     return (dx, dx_lp, None, None) if acc else (dx, dx_lp, dg, db)
 
 

@@ -146,7 +146,8 @@ int favit_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t
  *   models/vit.py:155,157,251; models/vit_mhla.py:45,64,88,107,188,241.
  * x is the fp32 residual stream with row stride ldx (lets the head normalise x[:,0]
  * only); y has dtype y_dtype; mean/rstd [rows] are saved for backward.
- * Backward: dx = LN'(dy) (+ dres if given); optional low-precision copy dx_lp; the
+ * Backward: dx = LN'(dy) (+ dres if given); optional low-precision copy dx_lp, optionally with the dropout mask
+ * (lp_dropout_p, lp_dropout_seed; element index row*D + col, as favit_dropout) of the branch it feeds; the
  * affine gradients are produced as `nparts` partial sums in a [2][nparts][D] workspace
  * (dbeta_part = dgamma_part + nparts*D) and folded deterministically (no atomics) into dgamma[D]
  * and dbeta[D] (accumulate=1 adds to them); dgamma = NULL skips the fold.
@@ -156,7 +157,8 @@ int favit_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const f
 int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x, int64_t ldx, const float* gamma,
                         const float* mean, const float* rstd, const float* dres, float* dx, int64_t lddx,
                         void* dx_lp, int lp_dtype, float* dgamma_part, float* dbeta_part, int32_t nparts,
-                        float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t D, void* stream);
+                        float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t D,
+                        float lp_dropout_p, uint64_t lp_dropout_seed, void* stream);
 /* out[c] (+)= sum_r in[r*ld + c] */
 int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t accumulate,
                       void* stream);

@@ -215,6 +215,48 @@ def test_train_mode_dropout_runs_and_is_stochastic(favit):
     assert torch.equal(m(x), m(x))
 
 
+@pytest.mark.parametrize("use_mhla", [True, False])
+def test_train_mode_dropout_gradients_match_finite_differences(favit, use_mhla):
+    """Train-mode dropout has no reference fixture (the masks come from this library's own counter-based generator),
+    but the seeds are drawn from torch's CPU generator: under a fixed torch.manual_seed the dropped model is a
+    deterministic function of its parameters, so the analytic gradients of the whole chain (embedding / attention /
+    projection / MLP dropouts recomputed in backward, the mask fused into the LayerNorm backward's low-precision copy)
+    must match central finite differences along random directions.  fp32 mode."""
+    favit.set_compute_dtype("fp32")
+    torch.manual_seed(11)
+    m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=3,
+                                                    num_heads=4, dropout=0.2, attn_dropout=0.2, embed_dropout=0.2,
+                                                    window_size=5, use_mhla=use_mhla).to(DEV).train()
+    x = torch.randn(6, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (6,), device=DEV)
+
+    def loss():
+        torch.manual_seed(1234)                      # same dropout seeds on every evaluation
+        return torch.nn.functional.cross_entropy(m(x).double(), y)
+
+    l0 = loss()
+    l0.backward()
+    assert float(loss().detach()) == float(l0.detach()), "a fixed torch seed must give the same masks"
+    params = [p for p in m.parameters()]
+    grads = [p.grad.detach().clone().double() for p in params]
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    for trial in range(4):
+        dirs = [torch.randn(p.shape, device=DEV, generator=gen) for p in params]
+        if trial == 3:                               # one direction confined to the last block (shallow path)
+            names = [n for n, _ in m.named_parameters()]
+            dirs = [d if ".2." in n else torch.zeros_like(d) for n, d in zip(names, dirs)]
+        analytic = sum(float((g * d.double()).sum()) for g, d in zip(grads, dirs))
+        eps = 1e-4                                   # (2e-3 is already 20 % off on this loss surface)
+        with torch.no_grad():
+            for p, d in zip(params, dirs): p.add_(d, alpha=eps)
+            lp = float(loss())
+            for p, d in zip(params, dirs): p.add_(d, alpha=-2 * eps)
+            lm = float(loss())
+            for p, d in zip(params, dirs): p.add_(d, alpha=eps)
+        numeric = (lp - lm) / (2 * eps)
+        assert abs(numeric - analytic) <= 5e-3 * max(abs(analytic), abs(numeric)) + 2e-3, (trial, numeric, analytic)
+
+
 @pytest.mark.parametrize("mode,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
 def test_full_size_cfg2_batch_independence(favit, mode, tol):
     """BASELINE.json configs[1] at its full size (B=256): every image is independent, so the
