@@ -144,6 +144,35 @@ __device__ __forceinline__ void stage_tile(char* tile, int rs, const T* base, lo
   }
 }
 
+// The same staging in two halves, so that the NEXT block's rows are in flight (in registers) while the current block
+// is being consumed: up to PF 16-byte chunks per thread and tile.
+constexpr int SDPA_PF = 2;
+template <typename T>
+__device__ __forceinline__ void tile_gload(uint4 (&r)[SDPA_PF], const T* base, long ld, int s0, int Ls, int hd, int cpr,
+                                           int nchunks, int tid) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+#pragma unroll
+  for (int j = 0; j < SDPA_PF; ++j) {
+    const int c = tid + 256 * j;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (c < nchunks) {
+      const int row = c / cpr, ch = c - row * cpr;
+      if (s0 + row < Ls && (ch + 1) * EPC <= hd) v = *reinterpret_cast<const uint4*>(base + (long)(s0 + row) * ld + ch * EPC);
+    }
+    r[j] = v;
+  }
+}
+__device__ __forceinline__ void tile_lstore(char* tile, int rs, const uint4 (&r)[SDPA_PF], int cpr, int nchunks, int tid) {
+#pragma unroll
+  for (int j = 0; j < SDPA_PF; ++j) {
+    const int c = tid + 256 * j;
+    if (c < nchunks) {
+      const int row = c / cpr, ch = c - row * cpr;
+      *reinterpret_cast<uint4*>(tile + row * rs + ch * 16) = r[j];
+    }
+  }
+}
+
 template <typename T, int NDT, int MODE>
 __global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -186,11 +215,55 @@ __global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
   const uint8_t* mrow_b = a.mask ? a.mask + (long)b * a.m_sb : nullptr;
   const int nchunk = hd_pad / M::KC;
 
+  // The owner rows' fragments do not change over the streamed blocks: with few chunks (bf16, head dim <= 128) they are
+  // read once.  (In the loop they were global loads in front of every block's first MFMA, and a wait for them is a
+  // wait for every older load as well -- vmcnt is in order -- which would also defeat the prefetch below.)
+  constexpr int HOIST = sizeof(T) == 2 ? 4 : 0;
+  const bool hoisted = HOIST > 0 && nchunk <= HOIST;
+  typename M::frag fo_h[HOIST > 0 ? HOIST : 1], fb_h[HOIST > 0 ? HOIST : 1];
+  if (hoisted) {
+#pragma unroll
+    for (int c = 0; c < HOIST; ++c) {
+      if (c < nchunk) {
+        fo_h[c] = M::slice_global(oa_row, c, g, hd);
+        if (MODE) fb_h[c] = M::slice_global(ob_row, c, g, hd);
+      }
+    }
+  }
+  // streamed rows of the NEXT block travel in registers while this block is consumed (small tiles only)
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cpr = hd_pad / EPC, nchunks = SB * cpr;
+  const bool pf = hoisted && nchunks <= SDPA_PF * 256 && !a.mask;
+  uint4 pra[SDPA_PF], prb[SDPA_PF];
+  if (pf) {
+    tile_gload<T>(pra, strA, strA_ld, 0, Ls, hd, cpr, nchunks, tid);
+    tile_gload<T>(prb, strB, strB_ld, 0, Ls, hd, cpr, nchunks, tid);
+  }
+
   for (int s0 = 0; s0 < Ls; s0 += SB) {
     __syncthreads();                                   // previous block's LDS reads are complete
-    stage_tile<T>(tileA, rs, strA, strA_ld, s0, Ls, hd, hd_pad, tid, SB);
-    stage_tile<T>(tileB, rs, strB, strB_ld, s0, Ls, hd, hd_pad, tid, SB);
+    if (pf) {
+      tile_lstore(tileA, rs, pra, cpr, nchunks, tid);
+      tile_lstore(tileB, rs, prb, cpr, nchunks, tid);
+    } else {
+      stage_tile<T>(tileA, rs, strA, strA_ld, s0, Ls, hd, hd_pad, tid, SB);
+      stage_tile<T>(tileB, rs, strB, strB_ld, s0, Ls, hd, hd_pad, tid, SB);
+    }
     __syncthreads();
+    // MODE 2: the streamed rows' statistics, loaded BEFORE the prefetch is issued (in-order vmcnt)
+    float lse_s[8], dl_s[8];
+    if (MODE == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int sr = min(s0 + 16 * (e >> 2) + 4 * g + (e & 3), Ls - 1);
+        lse_s[e] = a.lse[zq + sr];
+        dl_s[e] = a.delta[zq + sr];
+      }
+    }
+    if (pf && s0 + SB < Ls) {
+      tile_gload<T>(pra, strA, strA_ld, s0 + SB, Ls, hd, cpr, nchunks, tid);
+      tile_gload<T>(prb, strB, strB_ld, s0 + SB, Ls, hd, cpr, nchunks, tid);
+    }
 
     f32x4 t1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     f32x4 t2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -198,14 +271,28 @@ __global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
     const char* ra1 = tileA + (16 + n) * rs;
     const char* rb0 = tileB + n * rs;
     const char* rb1 = tileB + (16 + n) * rs;
-    for (int c = 0; c < nchunk; ++c) {
-      const typename M::frag fo = M::slice_global(oa_row, c, g, hd);
-      t1[0] = M::mma(M::slice_lds(ra0, c, g), fo, t1[0]);
-      if (SB == 32) t1[1] = M::mma(M::slice_lds(ra1, c, g), fo, t1[1]);
-      if (MODE) {
-        const typename M::frag fb = M::slice_global(ob_row, c, g, hd);
-        t2[0] = M::mma(M::slice_lds(rb0, c, g), fb, t2[0]);
-        if (SB == 32) t2[1] = M::mma(M::slice_lds(rb1, c, g), fb, t2[1]);
+    if (hoisted) {
+#pragma unroll
+      for (int c = 0; c < HOIST; ++c) {
+        if (c < nchunk) {
+          t1[0] = M::mma(M::slice_lds(ra0, c, g), fo_h[c], t1[0]);
+          if (SB == 32) t1[1] = M::mma(M::slice_lds(ra1, c, g), fo_h[c], t1[1]);
+          if (MODE) {
+            t2[0] = M::mma(M::slice_lds(rb0, c, g), fb_h[c], t2[0]);
+            if (SB == 32) t2[1] = M::mma(M::slice_lds(rb1, c, g), fb_h[c], t2[1]);
+          }
+        }
+      }
+    } else {
+      for (int c = 0; c < nchunk; ++c) {
+        const typename M::frag fo = M::slice_global(oa_row, c, g, hd);
+        t1[0] = M::mma(M::slice_lds(ra0, c, g), fo, t1[0]);
+        if (SB == 32) t1[1] = M::mma(M::slice_lds(ra1, c, g), fo, t1[1]);
+        if (MODE) {
+          const typename M::frag fb = M::slice_global(ob_row, c, g, hd);
+          t2[0] = M::mma(M::slice_lds(rb0, c, g), fb, t2[0]);
+          if (SB == 32) t2[1] = M::mma(M::slice_lds(rb1, c, g), fb, t2[1]);
+        }
       }
     }
 
@@ -249,9 +336,8 @@ __global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
       for (int e = 0; e < 8; ++e) {
         float lse_i = lse_o, dl_i = delta_o;
         if (MODE == 2) {
-          const int s = min(s0 + 16 * (e >> 2) + 4 * g + (e & 3), Ls - 1);
-          lse_i = a.lse[zq + s];
-          dl_i = a.delta[zq + s];
+          lse_i = lse_s[e];
+          dl_i = dl_s[e];
         }
         const float p = ok[e] ? __expf(sc[e] - lse_i) : 0.f;
         const float dp = t2[e >> 2][e & 3] * keep[e];
