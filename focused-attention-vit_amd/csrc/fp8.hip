@@ -62,13 +62,25 @@ __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ src
                                                        uint8_t* __restrict__ dst, long ld_dst,
                                                        uint8_t* __restrict__ dst_t, long ld_t,
                                                        const float* __restrict__ amax, float* __restrict__ scale_inv,
-                                                       float* __restrict__ colsum) {
+                                                       float* __restrict__ colsum, float* __restrict__ amax_next,
+                                                       float* __restrict__ amax_clear, int amax_n) {
   __shared__ uint8_t tile[64][64 + 4];
   __shared__ float csum[4][64];
+  __shared__ float wmax[4];
   constexpr float FMAX = FMT == FAVIT_E4M3 ? E4M3_MAX : E5M2_MAX;
-  const float am = amax[0];
+  // amax = the maximum over amax_n (1, or FAVIT_FP8_AMAX_SLOTS with delayed scaling) partial maxima: the previous
+  // call spread its atomics over that many addresses (tens of thousands of workgroups on ONE address serialise in
+  // one L2 channel: measured 20 -> 83 us for this kernel); they were final at its end, so plain (L1-cached) loads do
+  float am = 0.f;
+  for (int i = threadIdx.x & 63; i < amax_n; i += 64) am = fmaxf(am, amax[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
   const float scale = am > 0.f ? __fdiv_rn(FMAX, am) : 1.0f;           // IEEE division: reproducible scales
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_inv[0] = am > 0.f ? __fdiv_rn(am, FMAX) : 1.0f;
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0) scale_inv[0] = am > 0.f ? __fdiv_rn(am, FMAX) : 1.0f;
+    // delayed scaling: clear the slots the call after next accumulates into
+    if (amax_clear && threadIdx.x < FAVIT_FP8_AMAX_SLOTS) amax_clear[threadIdx.x] = 0.f;
+  }
   const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
   const int tr = threadIdx.x >> 2, tc = (threadIdx.x & 3) * 16;
   const long r = r0 + tr;
@@ -97,6 +109,15 @@ __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ src
         v[j] = (r < rows && c < cols) ? to_f32(src[r * ld + c]) : 0.f;
       }
     }
+  }
+  if (amax_next) {
+    // delayed scaling: this tensor's amax for the NEXT call of the same site, taken in the pass that quantises it
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) m = fmaxf(m, fabsf(v[j]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
   }
   if (colsum) {
     // column sums of the UNQUANTISED values: 16 rows per wave reduced by DPP-free shuffles, then LDS
@@ -133,6 +154,11 @@ __global__ __launch_bounds__(256) void quantize_kernel(const T* __restrict__ src
     for (int q = 0; q < 4; ++q) *reinterpret_cast<unsigned*>(&tile[tr][tc + 4 * q]) = w[q];
   }
   __syncthreads();
+  if (amax_next && threadIdx.x == 0) {
+    const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) & (FAVIT_FP8_AMAX_SLOTS - 1);
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax_next) + slot, __float_as_uint(m));
+  }
   if (colsum && threadIdx.x < 64) {
     const long c = c0 + threadIdx.x;
     if (c < cols) atomicAdd(colsum + c, csum[0][threadIdx.x] + csum[1][threadIdx.x] + csum[2][threadIdx.x] + csum[3][threadIdx.x]);
@@ -184,7 +210,10 @@ extern "C" int favit_fp8_amax(const void* src, int src_dtype, int64_t rows, int6
 
 extern "C" int favit_fp8_quantize(const void* src, int src_dtype, int64_t rows, int64_t cols, int64_t ld_src, void* dst,
                                   int64_t ld_dst, void* dst_t, int64_t ld_t, int fmt, const float* amax,
-                                  float* scale_inv, float* colsum, void* stream) {
+                                  float* scale_inv, float* colsum, float* amax_next, float* amax_clear, void* stream) {
+  // delayed scaling (amax_next given): amax, amax_next and amax_clear are arrays of FAVIT_FP8_AMAX_SLOTS floats
+  const int amax_n = amax_next ? FAVIT_FP8_AMAX_SLOTS : 1;
+  if ((amax_next == nullptr) != (amax_clear == nullptr)) return FAVIT_ERR_INVALID;
   if (!src || !amax || !scale_inv || rows <= 0 || cols <= 0 || ld_src < cols) return FAVIT_ERR_INVALID;
   if (!dst && !dst_t) return FAVIT_ERR_INVALID;
   if (dst && ld_dst < cols) return FAVIT_ERR_INVALID;
@@ -196,7 +225,8 @@ extern "C" int favit_fp8_quantize(const void* src, int src_dtype, int64_t rows, 
   dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rcover + 63) / 64));
 #define FAVIT_Q(T, F)                                                                                              \
   hipLaunchKernelGGL((quantize_kernel<T, F>), grid, dim3(256), 0, st, (const T*)src, (long)rows, (long)cols,        \
-                     (long)ld_src, (uint8_t*)dst, (long)ld_dst, (uint8_t*)dst_t, (long)ld_t, amax, scale_inv, colsum)
+                     (long)ld_src, (uint8_t*)dst, (long)ld_dst, (uint8_t*)dst_t, (long)ld_t, amax, scale_inv, colsum, \
+                     amax_next, amax_clear, amax_n)
   if (src_dtype == FAVIT_F32) {
     if (fmt == FAVIT_E4M3) FAVIT_Q(float, FAVIT_E4M3); else FAVIT_Q(float, FAVIT_E5M2);
   } else if (src_dtype == FAVIT_BF16) {

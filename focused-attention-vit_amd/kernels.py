@@ -173,27 +173,58 @@ def gemm_grouped_tn(problems, use_workspace: bool = True) -> bool:
 _FP8_DT = (torch.float8_e4m3fn, torch.float8_e5m2)
 
 
-def fp8_quantize(src: torch.Tensor, fmt: torch.dtype, *, want=True, want_t=False, colsum: Optional[torch.Tensor] = None):
+class Fp8History:
+    """Delayed per-tensor scaling state of one quantisation site: three rotating amax slots (this call's scale
+    comes from the amax the previous call measured; this call measures into the next slot and clears the one
+    after) and the scale_inv scalar the GEMM reads."""
+    __slots__ = ("slots", "scale_inv", "calls")
+
+    NSLOT = 256                                   # FAVIT_FP8_AMAX_SLOTS: partial maxima per array
+
+    def __init__(self, device):
+        self.slots = torch.zeros(3 * self.NSLOT, dtype=torch.float32, device=device)
+        self.scale_inv = torch.ones(1, dtype=torch.float32, device=device)
+        self.calls = 0
+
+
+def fp8_quantize(src: torch.Tensor, fmt: torch.dtype, *, want=True, want_t=False, colsum: Optional[torch.Tensor] = None,
+                 hist: Optional[Fp8History] = None):
     """Per-tensor scaled conversion of a [rows, cols] fp32 / bf16 matrix to OCP fp8 (`fmt` =
     torch.float8_e4m3fn | torch.float8_e5m2).  Returns (q [rows, cols] or None, q_t [cols, ld_t] or None
-    with ld_t = rows rounded up to 64 and the pad zero-filled, scale_inv device scalar).  The amax is
-    taken on the device in the same call sequence (no host sync).  colsum [cols] fp32 (optional) gets
+    with ld_t = rows rounded up to 64 and the pad zero-filled, scale_inv device scalar).  Without `hist` the amax is
+    taken on the device in the same call sequence (a separate pass, no host sync).  With `hist` (delayed scaling) the
+    scale comes from the amax the site's previous call measured and this call measures the next one while it
+    quantises: one pass over the tensor; values beyond the previous amax saturate.  colsum [cols] fp32 (optional) gets
     the column sums of src ADDED (bias gradient)."""
     require_gpu(src)
     if src.dim() != 2 or src.stride(1) != 1:
         raise ValueError("fp8_quantize expects a row-major 2-D matrix")
     rows, cols = src.shape
     dev = src.device
-    st = torch.zeros(2, dtype=torch.float32, device=dev)        # [amax, scale_inv]
     L = _abi.lib()
-    _abi.check(L.favit_fp8_amax(_p(src), dt(src), rows, cols, src.stride(0), _p(st), _st()), "favit_fp8_amax")
     q = torch.empty((rows, cols), dtype=fmt, device=dev) if want else None
     ld_t = (rows + 63) // 64 * 64
     q_t = torch.empty((cols, ld_t), dtype=fmt, device=dev) if want_t else None
-    _abi.check(L.favit_fp8_quantize(_p(src), dt(src), rows, cols, src.stride(0), _p(q), cols, _p(q_t), ld_t,
-                                    _abi.E5M2 if fmt == torch.float8_e5m2 else _abi.E4M3, _p(st),
-                                    C.c_void_p(st.data_ptr() + 4), _p(colsum), _st()), "favit_fp8_quantize")
-    return q, q_t, st[1:2]
+    f8 = _abi.E5M2 if fmt == torch.float8_e5m2 else _abi.E4M3
+    if hist is None:
+        st = torch.zeros(2, dtype=torch.float32, device=dev)        # [amax, scale_inv]
+        _abi.check(L.favit_fp8_amax(_p(src), dt(src), rows, cols, src.stride(0), _p(st), _st()), "favit_fp8_amax")
+        _abi.check(L.favit_fp8_quantize(_p(src), dt(src), rows, cols, src.stride(0), _p(q), cols, _p(q_t), ld_t, f8,
+                                        _p(st), C.c_void_p(st.data_ptr() + 4), _p(colsum), None, None, _st()),
+                   "favit_fp8_quantize")
+        return q, q_t, st[1:2]
+    base = hist.slots.data_ptr()
+    stride = 4 * hist.NSLOT
+    cur, nxt, clr = hist.calls % 3, (hist.calls + 1) % 3, (hist.calls + 2) % 3
+    if hist.calls == 0:                                             # no history yet: measure this tensor first
+        _abi.check(L.favit_fp8_amax(_p(src), dt(src), rows, cols, src.stride(0), C.c_void_p(base + stride * cur), _st()),
+                   "favit_fp8_amax")
+    hist.calls += 1
+    sinv = torch.empty(1, dtype=torch.float32, device=dev)          # per call: the GEMM reads it after later calls
+    _abi.check(L.favit_fp8_quantize(_p(src), dt(src), rows, cols, src.stride(0), _p(q), cols, _p(q_t), ld_t, f8,
+                                    C.c_void_p(base + stride * cur), _p(sinv), _p(colsum), C.c_void_p(base + stride * nxt),
+                                    C.c_void_p(base + stride * clr), _st()), "favit_fp8_quantize")
+    return q, q_t, sinv
 
 
 def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -29,6 +29,7 @@ extern "C" {
 #endif
 
 #define FAVIT_ABI_VERSION 4
+#define FAVIT_FP8_AMAX_SLOTS 256   /* partial maxima per tensor with delayed fp8 scaling (favit_fp8_quantize) */
 
 enum { FAVIT_F32 = 0, FAVIT_BF16 = 1, FAVIT_FP8 = 2 };
 /* OCP 8-bit float formats of gfx950 (NOT the MI300X fnuz encodings) */
@@ -130,13 +131,18 @@ int favit_gemm_grouped_tn_ws(const favit_gemm_t* gs, int32_t count, void* worksp
  *     dst_t [cols, ld_t]     transposed copy (NULL to skip); columns rows..ld_t-1 are zero-filled,
  *                            so ld_t (a multiple of 64) can serve as a padded GEMM K
  *     colsum [cols] fp32     optional: colsum[c] += sum_r src[r,c] (bias gradient of an fp8 Linear)
+ *     amax_next, amax_clear  optional, both or neither (delayed scaling).  Then amax, amax_next and amax_clear are
+ *                            three DIFFERENT arrays of FAVIT_FP8_AMAX_SLOTS floats (rotating roles): the scale comes
+ *                            from max(amax[0..]) -- what this site's previous call measured --, max |src| is taken in
+ *                            the same pass into amax_next (atomics spread over the slots), amax_clear is zeroed
+ *                            for the call after next.  No separate favit_fp8_amax pass.
  * src dtype is FAVIT_F32 or FAVIT_BF16, row stride ld_src (elements).
  * ---------------------------------------------------------------------------------- */
 int favit_fp8_amax(const void* src, int src_dtype, int64_t rows, int64_t cols, int64_t ld_src, float* amax,
                    void* stream);
 int favit_fp8_quantize(const void* src, int src_dtype, int64_t rows, int64_t cols, int64_t ld_src, void* dst,
                        int64_t ld_dst, void* dst_t, int64_t ld_t, int fmt, const float* amax, float* scale_inv,
-                       float* colsum, void* stream);
+                       float* colsum, float* amax_next, float* amax_clear, void* stream);
 
 /* dst[i] = (dst_dtype) src[i] */
 int favit_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
