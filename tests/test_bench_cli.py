@@ -1,0 +1,59 @@
+"""bench.py is the measurement contract (one JSON line per run): run it for real, small, on the GPU box -- every
+configuration, the dropout row, the fp8 mode and the CPU-baseline leg -- and check the line's shape."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(*args, timeout=600):
+    env = dict(os.environ)
+    env.pop("FAVIT_DP_FORCE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check(j, steps, warmup, dtype="bf16"):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["unit"] == "images/sec" and j["n_gpus"] == 1 and j["steps"] == steps and j["warmup"] == warmup
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["dtype"] == dtype and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
+    assert j["value"] > 0 and j["ms_per_step"] > 0
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("mfma", "hbm") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    import math
+    assert math.isfinite(j["loss"])
+
+
+@pytest.mark.parametrize("cfg,extra", [("cfg2", ["--batch", "16"]), ("cfg2", ["--batch", "16", "--dropout", "0.1"]),
+                                       ("cfg1", []), ("cfg3", ["--batch", "16"]),
+                                       ("cfg4", ["--batch", "2", "--dtype", "fp8"])])
+def test_bench_line(cfg, extra):
+    j = _run("--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *extra)
+    _check(j, 3, 1, dtype="fp8" if "fp8" in extra else "bf16")
+    assert j["config"]["baseline_config"] == cfg
+    if "--dropout" in extra:
+        assert j["config"]["dropout"] == 0.1
+
+
+def test_bench_cpu_baseline_leg():
+    """The oracle-timed CPU baseline (kind "port") on the small configuration."""
+    j = _run("--config", "cfg1", "--steps", "2", "--warmup", "1")
+    _check(j, 2, 1)
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
