@@ -57,3 +57,22 @@ def test_bench_cpu_baseline_leg():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
+
+
+def test_bench_two_ranks_gloo_on_one_gpu():
+    """The multi-rank flow of bench.py (rendezvous on 127.0.0.1, barriers, max-over-ranks timing, the collective
+    GEMM-trace steps, rank-0 JSON) with two ranks sharing the box's one GPU; gloo stands in for RCCL, which needs one
+    GPU per rank."""
+    env = dict(os.environ)
+    env.pop("FAVIT_DP_FORCE", None)
+    port = 36000 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--batch", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32 and j["config"]["parallelism"] == "dp2"
+    assert j["scaling"] == "weak" and j["value"] > 0 and "cpu_baseline" not in j
