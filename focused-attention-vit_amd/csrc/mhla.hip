@@ -1619,7 +1619,13 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
     (void)geometry(nblk, rbv, krows, ntl);
     a2.rb = rbv;
     nblk = (L + a2.rb - 1) / a2.rb;
-    const size_t lds = (size_t)2 * krows * rs + (size_t)2 * 16 * ntl * rs + (size_t)16 * ntl * 8;
+#ifdef FAVIT_PROBE
+    // FAVIT_MHLA_LDS_PAD=<bytes>: claim more LDS than needed (occupancy experiment: fewer workgroups per CU)
+    const size_t lds_pad = getenv("FAVIT_MHLA_LDS_PAD") ? (size_t)atoi(getenv("FAVIT_MHLA_LDS_PAD")) : 0;
+#else
+    constexpr size_t lds_pad = 0;
+#endif
+    const size_t lds = (size_t)2 * krows * rs + (size_t)2 * 16 * ntl * rs + (size_t)16 * ntl * 8 + lds_pad;
     if (lds <= 160 * 1024 && krows <= 108 && 16 * ntl <= 112) {
       dim3 grid(nblk, H, B);
       const bool plain = (mask == nullptr) && (a2.thresh == 0);
