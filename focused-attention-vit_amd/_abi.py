@@ -17,6 +17,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "favit.h")
 F32, BF16, FP8 = 0, 1, 2
 E4M3, E5M2 = 0, 1
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_SAVEGRAD, ACT_MULAUX = 0, 1, 2, 3, 4
+ERR_INVALID, ERR_UNSUPPORTED, ERR_ALIGN, ERR_LAUNCH = -1, -2, -3, -4
 POOL = {"mean": 0, "max": 1, "attention": 2}
 
 vp, i32, i64, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
@@ -57,6 +58,7 @@ _SIGS = {
     "favit_gemm_grouped_tn_workspace": ([C.POINTER(GemmDesc), i32], C.c_int64),
     "favit_gemm_grouped_tn_ws": ([C.POINTER(GemmDesc), i32, vp, i64, vp], C.c_int),
     "favit_cast": ([vp, C.c_int, vp, C.c_int, i64, vp], C.c_int),
+    "favit_gemm_residual_ln": ([vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i32, i64, f32, vp], C.c_int),
     "favit_fp8_amax": ([vp, C.c_int, i64, i64, i64, vp, vp], C.c_int),
     "favit_fp8_quantize": ([vp, C.c_int, i64, i64, i64, vp, i64, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp], C.c_int),
     "favit_layernorm_fwd": ([vp, i64, vp, vp, vp, C.c_int, vp, vp, i64, i32, f32, vp], C.c_int),
