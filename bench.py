@@ -336,7 +336,7 @@ def main():
             out["pcie_inclusive"] = pcie
         if trace:
             fam = {}
-            for e0, e1, fl, key, shp in trace:
+            for e0, e1, fl, key, shp, kern in trace:
                 d = fam.setdefault(key, [0.0, 0.0, 0])
                 d[0] += e0.elapsed_time(e1) * 1e-3
                 d[1] += fl

@@ -54,6 +54,7 @@ _SIGS = {
     "favit_abi_version": ([], C.c_int),
     "favit_strerror": ([C.c_int], C.c_char_p),
     "favit_gemm": ([C.POINTER(GemmDesc), vp], C.c_int),
+    "favit_gemm_last_kernel": ([], C.c_char_p),
     "favit_gemm_grouped_tn": ([C.POINTER(GemmDesc), i32, vp], C.c_int),
     "favit_gemm_grouped_tn_workspace": ([C.POINTER(GemmDesc), i32], C.c_int64),
     "favit_gemm_grouped_tn_ws": ([C.POINTER(GemmDesc), i32, vp, i64, vp], C.c_int),
@@ -85,7 +86,7 @@ _SIGS = {
     "favit_sppp_centroids": ([vp, vp, i32, i32, i32, vp], C.c_int),
     "favit_sppp_posenc_fwd": ([vp, vp, vp, i32, i32, i32, i32, vp], C.c_int),
     "favit_image_transform": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp], C.c_int),
-    "favit_slic_features": ([vp, vp, i32, i32, i32, f32, vp], C.c_int),
+    "favit_slic_features": ([vp, vp, i32, i32, i32, f32, vp, vp], C.c_int),
     "favit_slic_cluster_workspace": ([i32, i32], C.c_int64),
     "favit_slic_cluster": ([vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, vp, vp], C.c_int),
     "favit_slic_connect": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, vp], C.c_int),

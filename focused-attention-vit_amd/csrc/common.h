@@ -25,18 +25,27 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a (kernel, device) pair: it is set once per
-// pair (any number of devices per process, any number of host threads), not once per process.
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a (kernel, device) pair (any number of devices per
+// process, any number of host threads).  Callers pass run-time sizes (sdpa: head dim; mhla backward: L / rows per
+// block), so the LARGEST size set so far is remembered per pair and the attribute is raised when a later launch of
+// the same instantiation asks for more (a stale smaller limit makes that launch fail, in call-order-dependent ways).
+struct FavitDynLds { const void* kernel; int dev; int bytes; };
 static inline void favit_ensure_dyn_lds(const void* kernel, int bytes) {
   static std::mutex mu;
-  static std::vector<std::pair<const void*, int>> done;
+  static std::vector<FavitDynLds> done;
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(mu);
-  for (const auto& e : done)
-    if (e.first == kernel && e.second == dev) return;
+  for (auto& e : done)
+    if (e.kernel == kernel && e.dev == dev) {
+      if (bytes > e.bytes) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        e.bytes = bytes;
+      }
+      return;
+    }
   (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  done.emplace_back(kernel, dev);
+  done.push_back({kernel, dev, bytes});
 }
 
 template <typename T> struct dtype_of;

@@ -26,6 +26,9 @@
 #include <stdlib.h>
 
 namespace {
+// name of the kernel family the last favit_gemm / grouped launch of this host thread dispatched to
+// (favit_gemm_last_kernel: tests and bench.py read it to assert / report which kernel really ran)
+thread_local const char* g_last_kernel = "none";
 
 constexpr int BM = 128;
 constexpr int BN = 128;
@@ -1394,6 +1397,7 @@ __global__ __launch_bounds__(PP_THREADS) void gemm_bf16_pp_kernel(KParams p) {
 
 template <typename Kn>
 int launch_pp(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
+  g_last_kernel = "pp";
   favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), PP_LDS);
   hipLaunchKernelGGL(kernel, grid, dim3(PP_THREADS), PP_LDS, st, kp);
   FAVIT_CHECK_LAUNCH();
@@ -1499,6 +1503,7 @@ __global__ __launch_bounds__(P7_THREADS) void gemm_bf16_p7_kernel(KParams p) {
 
 template <typename Kn>
 int launch_p7(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
+  g_last_kernel = "p7";
   favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), P7_LDS);
   hipLaunchKernelGGL(kernel, grid, dim3(P7_THREADS), P7_LDS, st, kp);
   FAVIT_CHECK_LAUNCH();
@@ -1806,6 +1811,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_s64_kernel(KParams p) {
 
 template <typename Kn>
 int launch_s64(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
+  g_last_kernel = "s64";
   favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), S64_LDS);
   hipLaunchKernelGGL(kernel, grid, dim3(NTHREADS), S64_LDS, st, kp);
   FAVIT_CHECK_LAUNCH();
@@ -1880,6 +1886,7 @@ __global__ __launch_bounds__(256) void grouped_reduce_kernel(ReduceParams rp) {
 
 template <typename Kn>
 int launch_p4(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
+  g_last_kernel = "p4";
 #ifdef FAVIT_PROBE
   // FAVIT_GEMM_P4_ONE_PER_CU: claim 100 KiB of LDS so that only one workgroup fits a CU (occupancy experiment)
   static const int lds_bytes = getenv("FAVIT_GEMM_P4_ONE_PER_CU") ? 100 * 1024 : P4_LDS;
@@ -2069,6 +2076,7 @@ __global__ void zero_c_kernel(float* C, long M, long N, long ldc, long sCo, long
 
 template <typename K>
 int launch(K kernel, const KParams& kp, dim3 grid, hipStream_t st) {
+  g_last_kernel = "t128";
   favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), LDS_BYTES);
   hipLaunchKernelGGL(kernel, grid, dim3(NTHREADS), LDS_BYTES, st, kp);
   FAVIT_CHECK_LAUNCH();
@@ -2115,6 +2123,8 @@ unsigned long long* g_probe_buffer = nullptr;
 // probe build only (not declared in include/favit.h): device buffer of >= grid * 8 * 5 uint64 for the pp stamps
 extern "C" void favit_probe_buffer(void* buf) { g_probe_buffer = reinterpret_cast<unsigned long long*>(buf); }
 #endif
+
+extern "C" const char* favit_gemm_last_kernel(void) { return g_last_kernel; }
 
 extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   if (!g || !g->A || !g->B || !g->C) return FAVIT_ERR_INVALID;

@@ -8,8 +8,13 @@
 // spatial^2 / step^2 + (dLab / compactness)^2, max_num_iter iterations, connectivity enforcement with
 // min_size_factor 0.5) with every decision after the colour conversion in INTEGER arithmetic, so the result is
 // deterministic and reproducible bit for bit by the CPU restatement oracle/slic_oracle.py:
-//   stage 1  favit_slic_features : gaussian blur (reflect boundary, radius int(4 sigma + 0.5)) + sRGB -> CIELAB,
-//            quantised to 1/16 units (int16 x 4 per pixel).  Float work: compared with a tolerance.
+//   stage 1  favit_slic_features : per-image min-max rescale of the input to [0, 1] over all three channels
+//            (scikit-image >= 0.19 does this first, "to make choice of compactness insensitive to input image scale";
+//            the reference feeds mean/std-NORMALISED tensors, values ~ -2 .. 2.6, so without it the Lab conversion and
+//            the meaning of compactness = 0.1 would differ from the reference's call), gaussian blur (reflect boundary,
+//            radius int(4 sigma + 0.5)) + sRGB -> CIELAB, quantised to 1/16 units (int16 x 4 per pixel).  Float work:
+//            compared with a tolerance.  The blur is linear with weights summing to 1, so the rescale is applied to
+//            the blurred value.  minmax = NULL skips the rescale (the behaviour of scikit-image < 0.19).
 //   stage 2  favit_slic_cluster  : k-means in (y, x, L, a, b), fixed point (1/16 pixel, 1/16 Lab), int64 distances
 //            16^2 * spatial^2 + coef * dq^2 with coef = round(step^2 / compactness^2), first-minimum ties, centres =
 //            truncated integer means.  One assignment launch over every pixel of every image + one centre update per
@@ -41,8 +46,30 @@ __device__ __forceinline__ float srgb_to_linear(float c) {
 }
 __device__ __forceinline__ float lab_f(float t) { return t > 0.008856f ? cbrtf(t) : 7.787f * t + 16.0f / 116.0f; }
 
+// per-image minimum and maximum over all channels: one 1024-thread workgroup per image (3*H*W floats, ~150 per thread)
+__global__ __launch_bounds__(1024) void slic_minmax_kernel(const float* __restrict__ img, float* __restrict__ minmax, long n) {
+  const float* im = img + (long)blockIdx.x * n;
+  float lo = INFINITY, hi = -INFINITY;
+  for (long i = threadIdx.x; i < n; i += 1024) {
+    const float v = im[i];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  lo = -wave_max(-lo);
+  hi = wave_max(hi);
+  __shared__ float slo[16], shi[16];
+  if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) { lo = fminf(lo, slo[w]); hi = fmaxf(hi, shi[w]); }
+    minmax[2 * blockIdx.x] = lo;
+    minmax[2 * blockIdx.x + 1] = hi;
+  }
+}
+
 __global__ __launch_bounds__(256) void slic_features_kernel(const float* __restrict__ img, short* __restrict__ feat, int B,
-                                                            int H, int W, float sigma, int radius) {
+                                                            int H, int W, float sigma, int radius,
+                                                            const float* __restrict__ minmax) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   const long HW = (long)H * W;
   if (p >= (long)B * HW) return;
@@ -63,6 +90,14 @@ __global__ __launch_bounds__(256) void slic_features_kernel(const float* __restr
         const float w = wy * (__expf(-0.5f * dx * dx / (sigma * sigma)) / wsum);
         for (int c = 0; c < 3; ++c) rgb[c] = fmaf(w, im[c * HW + (long)yy * W + xx], rgb[c]);
       }
+    }
+  }
+  if (minmax) {                      // image -= min; image /= (max - min)  unless the image is constant
+    const float lo = minmax[2 * b], hi = minmax[2 * b + 1];
+    const float range = hi - lo;
+    for (int c = 0; c < 3; ++c) {
+      rgb[c] -= lo;
+      if (range != 0.f) rgb[c] = __fdiv_rn(rgb[c], range);
     }
   }
   const float r = srgb_to_linear(rgb[0]), g = srgb_to_linear(rgb[1]), bl = srgb_to_linear(rgb[2]);
@@ -303,13 +338,18 @@ __global__ __launch_bounds__(256) void cc_output_kernel(const uint8_t* __restric
 
 }  // namespace
 
-extern "C" int favit_slic_features(const float* img, int16_t* feat, int32_t B, int32_t H, int32_t W, float sigma, void* stream) {
+extern "C" int favit_slic_features(const float* img, int16_t* feat, int32_t B, int32_t H, int32_t W, float sigma,
+                                   float* minmax, void* stream) {
   if (!img || !feat || B <= 0 || H <= 0 || W <= 0 || sigma < 0.f) return FAVIT_ERR_INVALID;
   const int radius = sigma > 0.f ? (int)(4.0f * sigma + 0.5f) : 0;
   if (radius > 32) return FAVIT_ERR_UNSUPPORTED;
   const long n = (long)B * H * W;
+  if (minmax) {
+    hipLaunchKernelGGL(slic_minmax_kernel, dim3((unsigned)B), dim3(1024), 0, as_stream(stream), img, minmax, 3L * H * W);
+    FAVIT_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(slic_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), img,
-                     reinterpret_cast<short*>(feat), B, H, W, sigma, radius);
+                     reinterpret_cast<short*>(feat), B, H, W, sigma, radius, (const float*)minmax);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }

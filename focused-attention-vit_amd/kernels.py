@@ -19,7 +19,7 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 # bench.py sets this to a list to time every favit_gemm launch with HIP events recorded on the
 # stream the kernel is launched on (torch's current stream): entries are
-# (start_event, end_event, algorithmic_flops, kernel_key).
+# (start_event, end_event, algorithmic_flops, kernel_key, shape, kernel family the library dispatched to).
 GEMM_TRACE = None
 
 
@@ -116,7 +116,7 @@ def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias
     e1.record()
     key = ("fp8" if fp8 else "bf16" if A.dtype == torch.bfloat16 else "f32") + ("_K" if a_kmajor else "_M") + ("K" if b_kmajor else "M") + \
           ("_obf16" if Cc.dtype == torch.bfloat16 else "_of32")
-    GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, key, (M, N, K, batch)))
+    GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, key, (M, N, K, batch), _abi.lib().favit_gemm_last_kernel().decode()))
 
 
 _GROUPED_WS = {}          # device index -> workspace tensor of the slab-mode split-K reduction
@@ -166,7 +166,7 @@ def gemm_grouped_tn(problems, use_workspace: bool = True) -> bool:
     if GEMM_TRACE is not None:
         e1.record()
         fl = sum(2.0 * p[0].shape[0] * p[0].shape[1] * p[1].shape[1] for p in problems)
-        GEMM_TRACE.append((e0, e1, fl, "bf16_MM_of32_grouped", (len(problems),)))
+        GEMM_TRACE.append((e0, e1, fl, "bf16_MM_of32_grouped", (len(problems),), "grouped_tn"))
     return True
 
 
@@ -533,9 +533,13 @@ def slic_grid(H, W, n_segments):
     return ys, xs, max(max(1, int(round(sy))), max(1, int(round(sx))))
 
 
-def slic(images, n_segments=16, compactness=0.1, sigma=1.0, max_num_iter=10, min_size_factor=0.5, stages=False):
+def slic(images, n_segments=16, compactness=0.1, sigma=1.0, max_num_iter=10, min_size_factor=0.5, stages=False,
+         rescale=True):
     """SLIC label maps [B,H,W] int64 of fp32 images [B,3,H,W] on the device (csrc/slic.hip; parity with
-    scikit-image unpinned, see include/favit.h).  stages=True also returns (feat, cluster_labels, n_regions)."""
+    scikit-image unpinned, see include/favit.h).  stages=True also returns (feat, cluster_labels, n_regions).
+    rescale (default, scikit-image >= 0.19): every image is first rescaled to [0, 1] by its own min / max over all
+    channels, so mean/std-normalised inputs (what the reference's models pass) segment like their [0, 1] originals;
+    rescale=False restates scikit-image < 0.19, which takes the values as sRGB in [0, 1] as they are."""
     require_gpu(images)
     if images.dim() != 4 or images.shape[1] != 3 or images.dtype != torch.float32:
         raise TypeError("slic expects fp32 images [B, 3, H, W]")
@@ -555,7 +559,8 @@ def slic(images, n_segments=16, compactness=0.1, sigma=1.0, max_num_iter=10, min
     out = torch.empty((B, H, W), dtype=torch.int64, device=dev)
     nreg = torch.empty(B, dtype=torch.int32, device=dev)
     L = _abi.lib()
-    _abi.check(L.favit_slic_features(_p(images), _p(feat), B, H, W, float(sigma), _st()), "favit_slic_features")
+    mm = torch.empty((B, 2), dtype=torch.float32, device=dev) if rescale else None
+    _abi.check(L.favit_slic_features(_p(images), _p(feat), B, H, W, float(sigma), _p(mm), _st()), "favit_slic_features")
     cws = torch.empty(int(L.favit_slic_cluster_workspace(Kc, B)) // 8 + 1, dtype=torch.int64, device=dev)
     _abi.check(L.favit_slic_cluster(_p(feat), _p(lab), _p(init), Kc, B, H, W, step, coef, max_num_iter, _p(cws), _st()),
                "favit_slic_cluster")
@@ -582,8 +587,9 @@ def slic_stage_times(images, n_segments=16, compactness=0.1, sigma=1.0, max_num_
     nreg = torch.empty(B, dtype=torch.int32, device=dev)
     L = _abi.lib()
     cws = torch.empty(int(L.favit_slic_cluster_workspace(Kc, B)) // 8 + 1, dtype=torch.int64, device=dev)
+    mm = torch.empty((B, 2), dtype=torch.float32, device=dev)
     stages = [
-        ("features", lambda: L.favit_slic_features(_p(images), _p(feat), B, H, W, float(sigma), _st())),
+        ("features", lambda: L.favit_slic_features(_p(images), _p(feat), B, H, W, float(sigma), _p(mm), _st())),
         ("cluster", lambda: L.favit_slic_cluster(_p(feat), _p(lab), _p(init), Kc, B, H, W, step, coef, max_num_iter, _p(cws), _st())),
         ("connect", lambda: L.favit_slic_connect(_p(lab), _p(ws[0]), _p(ws[1]), _p(o), _p(nreg), B, H, W, min_size, _st())),
     ]

@@ -4,10 +4,12 @@ SuperpixelPooling, DynamicPositionalEncoding, SPPPViT).
 The reference runs mapping / pooling / centroids as per-image, per-patch Python loops with a
 device sync per patch; here they are batched device kernels (csrc/sppp.hip).  The dict-based
 per-image API of the reference is kept (``map_patches`` returns the same ordered dict) and a
-batched device API is added for the model fast path.  SLIC itself (skimage, unpinned in the
-reference and absent from the image) is out of scope: ``SuperpixelSegmentation.segment`` calls
-skimage if it is importable, otherwise a label-map provider must be installed
-(``model.segmentation.set_label_maps(...)`` or assigning ``segment``)."""
+batched device API is added for the model fast path.  ``SuperpixelSegmentation.segment`` runs SLIC on the
+device for GPU images (csrc/slic.hip: the published algorithm as scikit-image >= 0.19 parametrises it, including
+its per-image min-max rescale of the input; parity with scikit-image itself is UNPINNED -- it is not importable here
+and the reference holds no label-map fixture), returns installed label maps if there are any
+(``model.segmentation.set_label_maps(...)``, the way to reproduce segmentations computed elsewhere), and calls
+scikit-image for CPU images like the reference does."""
 import math
 from typing import Dict, List, Optional
 
@@ -26,6 +28,7 @@ class SuperpixelSegmentation:
         self.compactness = compactness
         self.sigma = sigma
         self._maps = None
+        self.rescale_input = True      # scikit-image >= 0.19 rescales every image to [0, 1] first; False = < 0.19
 
     def set_label_maps(self, maps: Optional[torch.Tensor]):
         """Install precomputed label maps [B,H,W] (int64) returned by the next segment() calls."""
@@ -41,7 +44,8 @@ class SuperpixelSegmentation:
         batch_mode = image.dim() == 4
         imgs = image if batch_mode else image[None]
         if imgs.is_cuda:
-            seg = K.slic(imgs.float(), n_segments=self.num_segments, compactness=self.compactness, sigma=self.sigma)
+            seg = K.slic(imgs.float(), n_segments=self.num_segments, compactness=self.compactness, sigma=self.sigma,
+                         rescale=self.rescale_input)
             return seg if batch_mode else seg[0]
         try:
             from skimage.segmentation import slic

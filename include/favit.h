@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FAVIT_ABI_VERSION 4
+#define FAVIT_ABI_VERSION 5
 #define FAVIT_FP8_AMAX_SLOTS 256   /* partial maxima per tensor with delayed fp8 scaling (favit_fp8_quantize) */
 
 enum { FAVIT_F32 = 0, FAVIT_BF16 = 1, FAVIT_FP8 = 2 };
@@ -106,6 +106,9 @@ typedef struct favit_gemm_t {
 } favit_gemm_t;
 
 int favit_gemm(const favit_gemm_t* g, void* stream);
+/* Diagnostic: the kernel family ("p4" 256x128 tiles, "p7" 256x256, "pp" ping-pong, "s64" 64-row, "t128"
+ * 128x128 / exact-fp32) the calling host thread's last favit_gemm dispatched to.  Static string, never NULL. */
+const char* favit_gemm_last_kernel(void);
 
 /* Grouped weight-gradient GEMMs: `count` (<= 8) problems dW_i = dY_i^T . X_i that share the token
  * dimension K (e.g. the four nn.Linear layers of one transformer block) as ONE launch.  Every
@@ -244,7 +247,10 @@ int favit_image_transform(const uint8_t* src, uint8_t* tmp, float* out, uint8_t*
  * dependency absent from the image: parity with skimage is UNPINNED; the algorithm (csrc/slic.hip header) is the
  * published SLIC as skimage parametrises it, integer-exact after the colour conversion, and is checked against
  * the CPU restatement oracle/slic_oracle.py.
- *   features: img fp32 [B,3,H,W] -> feat int16 [B,H*W,4] = round(16 * CIELAB(gaussian_sigma(img))), lane 3 = 0
+ *   features: img fp32 [B,3,H,W] -> feat int16 [B,H*W,4] = round(16 * CIELAB(gaussian_sigma(rescale(img)))), lane 3 = 0;
+ *             minmax: device workspace of 2*B floats -> every image is first rescaled to [0, 1] by its own minimum and
+ *             maximum over all channels, as scikit-image >= 0.19 does before smoothing (the reference passes
+ *             mean/std-normalised tensors, models/sppp_mhla.py:278); NULL = no rescale (scikit-image < 0.19)
  *   cluster : k-means, K <= 64 centres seeded at init_yx [K,2] (int32 y, x), window +-2*step, distance
  *             256*spatial^2 + coef*dq^2 (int64), `iters` rounds -> labels uint8 [B,H*W]; ws: 8-byte aligned device
  *             workspace of favit_slic_cluster_workspace(K, B) bytes (per-centre sums and coordinates)
@@ -252,7 +258,8 @@ int favit_image_transform(const uint8_t* src, uint8_t* tmp, float* out, uint8_t*
  *             consecutive labels from 0 -> out int64 [B,H*W]; n_regions int32 [B] (-1: more than 2048 components,
  *             out = the cluster map); ws_comp / ws_aux: int32 [B,H*W] workspaces.
  * ---------------------------------------------------------------------------------- */
-int favit_slic_features(const float* img, int16_t* feat, int32_t B, int32_t H, int32_t W, float sigma, void* stream);
+int favit_slic_features(const float* img, int16_t* feat, int32_t B, int32_t H, int32_t W, float sigma, float* minmax,
+                        void* stream);
 int64_t favit_slic_cluster_workspace(int32_t K, int32_t B);
 int favit_slic_cluster(const int16_t* feat, uint8_t* labels, const int32_t* init_yx, int32_t K, int32_t B, int32_t H,
                        int32_t W, int32_t step, int64_t coef, int32_t iters, void* ws, void* stream);

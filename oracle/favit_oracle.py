@@ -356,6 +356,74 @@ def sppp_vit_mhla_forward(x: Tensor, segmaps: np.ndarray, sd: SD, P: int, H: int
     return linear(t, sd["head.weight"], sd["head.bias"])
 
 
+def _sppp_front(x: Tensor, segmaps: np.ndarray, sd: SD, P: int, S: int, kind: str, emb: Tensor) -> Tensor:
+    """Steps 3-6 shared by every SPPP model (models/sppp.py:452-484, models/sppp_mhla.py:286-304,
+    models/mhla_models.py:226-253, models/attention.py:565-590): pool per image, prepend CLS, centroid pos-enc."""
+    B, _, img, _ = x.shape
+    pooled = torch.stack([pool(emb[b], map_patches(segmaps[b], img, P), kind) for b in range(B)])
+    t = torch.cat((sd["cls_token"].expand(B, -1, -1), pooled), dim=1)
+    return dynamic_posenc(t, superpixel_centroids(segmaps, S))
+
+
+def _head(t: Tensor, sd: SD) -> Tensor:
+    return linear(layer_norm(t, sd["norm.weight"], sd["norm.bias"])[:, 0], sd["head.weight"], sd["head.bias"])
+
+
+def pretrained_vit_mhla_forward(x: Tensor, sd: SD, P: int, H: int, W: int) -> Tensor:
+    """PretrainedViTWithMHLA.forward (models/mhla_models.py:120-166): the ViT skeleton over
+    MHLATransformerBlock (mlp = nn.Sequential, keys mlp.0 / mlp.3)."""
+    B = x.shape[0]
+    t = patch_embed(x, sd, "patch_embed.", P)
+    t = torch.cat((sd["cls_token"].expand(B, -1, -1), t), dim=1) + sd["pos_embed"]
+    for i in range(_depth(sd)):
+        t = mhla_block(t, sd, f"blocks.{i}.", H, W)
+    return _head(t, sd)
+
+
+def pretrained_sppp_vit_mhla_forward(x: Tensor, segmaps: np.ndarray, sd: SD, P: int, H: int, W: int, S: int = 16,
+                                     kind: str = "mean") -> Tensor:
+    """PretrainedSPPPViTWithMHLA.forward (models/mhla_models.py:207-268) with the label maps given."""
+    t = _sppp_front(x, segmaps, sd, P, S, kind, patch_embed(x, sd, "patch_embed.", P))
+    for i in range(_depth(sd)):
+        t = mhla_block(t, sd, f"blocks.{i}.", H, W)
+    return _head(t, sd)
+
+
+def sppp_vit_forward(x: Tensor, segmaps: np.ndarray, sd: SD, P: int, H: int, S: int = 16, kind: str = "mean") -> Tensor:
+    """SPPPViT.forward (models/sppp.py:430-500) over vit.TransformerBlock -- the reference's constructor raises
+    (sppp.py:378 names a class that does not exist), so this restates the evident intent: NO reference output
+    exists for it; every piece it is composed of is pinned on its own."""
+    t = _sppp_front(x, segmaps, sd, P, S, kind, patch_embed(x, sd, "patch_embed.", P))
+    for i in range(_depth(sd)):
+        t = vit_block(t, sd, f"blocks.{i}.", H)
+    return _head(t, sd)
+
+
+def conv_patch_embed(x: Tensor, sd: SD, p: str, P: int) -> Tensor:
+    """nn.Conv2d(C, D, kernel = stride = P) -> flatten(2) -> transpose(1, 2) (models/attention.py:271-276,450-455)."""
+    return torch.nn.functional.conv2d(x, sd[f"{p}0.weight"], sd[f"{p}0.bias"], stride=P).flatten(2).transpose(1, 2)
+
+
+def cross_vit_forward(x: Tensor, sd: SD, P: int, H: int, multi_head: bool) -> Tensor:
+    """CrossAttentionViT.forward (models/attention.py:325-372; block(x, x), :350).  Constructor raises in the
+    reference (nn.Transpose, attention.py:275): evident intent, no reference output."""
+    B = x.shape[0]
+    t = conv_patch_embed(x, sd, "patch_embed.", P)
+    t = torch.cat((sd["cls_token"].expand(B, -1, -1), t), dim=1) + sd["pos_embed"]
+    for i in range(_depth(sd)):
+        t = cross_block(t, t, sd, f"blocks.{i}.", H, multi_head)
+    return _head(t, sd)
+
+
+def cross_sppp_vit_forward(x: Tensor, segmaps: np.ndarray, sd: SD, P: int, H: int, multi_head: bool, S: int = 16,
+                           kind: str = "mean") -> Tensor:
+    """CrossAttentionSPPPViT.forward (models/attention.py:540-609); same caveat as cross_vit_forward."""
+    t = _sppp_front(x, segmaps, sd, P, S, kind, conv_patch_embed(x, sd, "patch_embed.", P))
+    for i in range(_depth(sd)):
+        t = cross_block(t, t, sd, f"blocks.{i}.", H, multi_head)
+    return _head(t, sd)
+
+
 def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     """nn.CrossEntropyLoss() mean reduction (experiments/mhla_pretrained.py:329,365)."""
     lse = torch.logsumexp(logits, dim=-1)

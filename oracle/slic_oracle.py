@@ -1,7 +1,8 @@
 """CPU restatement of the device SLIC (focused-attention-vit_amd/csrc/slic.hip) -- TEST INFRASTRUCTURE ONLY.
 
 Only tests/ may import this module; the product never does.  PARITY UNPINNED with respect to the reference's own
-segmentation: the reference calls skimage.segmentation.slic (models/sppp.py:64-66), scikit-image is not pinned by
+segmentation (restated from the published algorithm and scikit-image >= 0.19's parametrisation of it, whose first
+step -- the per-image min-max rescale to [0, 1] -- is included): the reference calls skimage.segmentation.slic (models/sppp.py:64-66), scikit-image is not pinned by
 the reference and not importable in this image, and the reference holds no fixture of a label map.  This file restates
 the PUBLISHED algorithm (Achanta et al. 2012 as scikit-image parametrises it: gaussian pre-smoothing, CIELAB, seeds on
 skimage.util.regular_grid, 2*step search windows, distance spatial^2/step^2 + (dLab/compactness)^2, max_num_iter
@@ -30,10 +31,18 @@ def regular_grid_2d(H, W, n_segments):
     return ys, xs, max(max(1, int(round(sy))), max(1, int(round(sx))))
 
 
-def features(img, sigma):
-    """img float [3,H,W] -> int16 [H*W,3]: round(16 * Lab(gaussian(img))) (float64 here; the device works in fp32)."""
-    img = np.asarray(img, dtype=np.float64)
+def features(img, sigma, rescale=True):
+    """img float [3,H,W] -> int16 [H*W,3]: round(16 * Lab(gaussian(rescale(img)))) (float64 here; the device works
+    in fp32).  rescale: scikit-image >= 0.19's first step, `image -= image.min(); image /= (max - min)` over the whole
+    array (all channels), skipped for a constant image (skimage/segmentation/slic_superpixels.py, "Rescale image to
+    [0, 1] to make choice of compactness insensitive to input image scale")."""
+    img = np.array(img, dtype=np.float64)
     _, H, W = img.shape
+    if rescale:
+        lo, hi = img.min(), img.max()
+        img -= lo
+        if hi != lo:
+            img /= (hi - lo)
     r = int(4.0 * sigma + 0.5) if sigma > 0 else 0
     if r > 0:
         k = np.exp(-0.5 * (np.arange(-r, r + 1) ** 2) / (sigma * sigma))

@@ -47,6 +47,7 @@ from models import vit_mhla as rvm                  # noqa: E402
 from models import attention as ratt                # noqa: E402
 from models import sppp as rsppp                    # noqa: E402
 from models import sppp_mhla as rsm                 # noqa: E402
+from models import mhla_models as rmm               # noqa: E402
 
 from oracle.favit_oracle import voronoi_labels      # noqa: E402  (input generator only)
 
@@ -383,6 +384,49 @@ def gen_configs():
     save("configs.npz", out)
 
 
+def gen_wrappers():
+    """The two whole-model wrappers of models/mhla_models.py that the reference CAN construct (with an odd
+    window_size; its default 4 crashes at the first forward).  SPPPViT, CrossAttentionViT and CrossAttentionSPPPViT
+    raise in their constructors in the reference (sppp.py:378, attention.py:275,454): no fixture is possible."""
+    out = {}
+    ce = torch.nn.CrossEntropyLoss()
+    torch.manual_seed(77)
+    m = rmm.PretrainedViTWithMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2, num_heads=4,
+                                  window_size=7)
+    m.eval()
+    x = torch.randn(3, 3, 32, 32)
+    y = torch.randint(0, 10, (3,))
+    logits = m(x)
+    loss = ce(logits, y)
+    loss.backward()
+    out["pvit/x"], out["pvit/y"] = x.numpy(), y.numpy()
+    out["pvit/logits"], out["pvit/loss"] = np32(logits), np32(loss)
+    out["pvit/param_sum"] = np.float64(sum(p.double().sum().item() for p in m.parameters()))
+    out["pvit/n_params"] = np.int64(m.get_num_parameters())
+    out["pvit/sd_keys"] = np.asarray(list(m.state_dict().keys()))
+    _gnorms(out, "pvit", m)
+    # SPPP wrapper: 64x64 images, 16x16 patches (4x4 grid), 4 superpixels; label maps are inputs
+    maps = _maps_with_R(64, 16, 4, 4, 2, 300)
+    segs = torch.from_numpy(np.stack([sm for _, sm in maps]))
+    out["psppp/segmaps"] = segs.numpy().astype(np.uint8)
+    for kind in ("mean", "max", "attention"):
+        torch.manual_seed(78)
+        m = rmm.PretrainedSPPPViTWithMHLA(img_size=64, patch_size=16, num_classes=10, embed_dim=64, depth=2, num_heads=4,
+                                          window_size=3, num_superpixels=4, pooling_type=kind)
+        m.eval()
+        m.segmentation.segment = lambda x, _s=segs: _s
+        x = torch.randn(2, 3, 64, 64)
+        y = torch.randint(0, 10, (2,))
+        logits = m(x)
+        loss = ce(logits, y)
+        loss.backward()
+        out[f"psppp_{kind}/x"], out[f"psppp_{kind}/y"] = x.numpy(), y.numpy()
+        out[f"psppp_{kind}/logits"], out[f"psppp_{kind}/loss"] = np32(logits), np32(loss)
+        out[f"psppp_{kind}/param_sum"] = np.float64(sum(p.double().sum().item() for p in m.parameters()))
+        _gnorms(out, f"psppp_{kind}", m)
+    save("wrappers.npz", out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_windows()
@@ -392,3 +436,4 @@ if __name__ == "__main__":
     gen_sppp()
     gen_models()
     gen_configs()
+    gen_wrappers()

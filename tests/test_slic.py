@@ -88,6 +88,50 @@ def test_device_slic_stages_match_the_oracle(favit, H, W, nseg, sigma, compactne
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rescale", [True, False])
+def test_device_slic_on_mean_std_normalised_inputs(favit, rescale):
+    """The reference's models hand SLIC their mean/std-NORMALISED input (models/sppp_mhla.py:278): values of about
+    -2.1 .. 2.6.  scikit-image >= 0.19 rescales every image to [0, 1] by its own min / max first (rescale=True, the
+    default here); < 0.19 does not (rescale=False: negative values go through sRGB -> Lab as they are).  Both forms:
+    float stage within +-1 quantisation step of the fp64 restatement, integer stages bit-exact; and with the rescale
+    a global affine change of the input (a * x + b, a > 0) leaves the features unchanged."""
+    K = favit.kernels
+    H = W = 96
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32)[:, None, None]
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32)[:, None, None]
+    imgs = np.stack([(_smooth_image(H, W, 40 + i) - mean) / std for i in range(3)]).astype(np.float32)
+    assert imgs.min() < -1.0 and imgs.max() > 1.5
+    out, feat, lab, nreg = K.slic(torch.from_numpy(imgs).to(DEV), n_segments=9, compactness=1.0, sigma=1.0, stages=True,
+                                  rescale=rescale)
+    ys, xs, step = SO.regular_grid_2d(H, W, 9)
+    coef = int(round((step / 1.0) ** 2))
+    min_size = int(0.5 * (H * W / float(len(ys) * len(xs))))
+    feat, lab, out = feat.cpu().numpy(), lab.cpu().numpy(), out.cpu().numpy()
+    for b in range(3):
+        ref_f = SO.features(imgs[b], 1.0, rescale=rescale)
+        diff = np.abs(feat[b, :, :3].astype(np.int64) - ref_f.astype(np.int64))
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.95, (rescale, diff.max(), (diff == 0).mean())
+        ref_l = SO.cluster(feat[b, :, :3], H, W, ys, xs, step, coef, iters=10)
+        np.testing.assert_array_equal(lab[b].reshape(-1), ref_l)
+        ref_o, _ = SO.connect(lab[b].reshape(-1), H, W, min_size)
+        np.testing.assert_array_equal(out[b].reshape(-1), ref_o)
+    if rescale:
+        _, feat2, _, _ = K.slic(torch.from_numpy(3.5 * imgs - 0.7).to(DEV), n_segments=9, compactness=1.0, sigma=1.0,
+                                stages=True)
+        d = np.abs(feat2.cpu().numpy().astype(np.int64) - feat.astype(np.int64))
+        assert d.max() <= 1 and (d == 0).mean() > 0.98, (d.max(), (d == 0).mean())
+        # the segmentation model uses the rescaled form by default and exposes the opt-out
+        seg = favit.models.sppp.SuperpixelSegmentation(num_segments=9, compactness=1.0)
+        assert seg.rescale_input is True
+        a = seg.segment(torch.from_numpy(imgs).to(DEV))
+        np.testing.assert_array_equal(a.cpu().numpy(), out)
+    # a constant image (max == min) is not divided by zero: one flat Lab value, seed-grid Voronoi squares
+    flat = torch.full((1, 3, 64, 64), -0.3, device=DEV)
+    seg = K.slic(flat, n_segments=16, rescale=rescale)[0]
+    assert int(seg.max()) == 15 and torch.isfinite(seg.float()).all()
+
+
+@pytest.mark.gpu
 def test_device_slic_ground_truth_and_properties(favit):
     from scipy import ndimage
     K = favit.kernels

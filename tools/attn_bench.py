@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 pkg = importlib.import_module("focused-attention-vit_amd")
 if os.environ.get("FAVIT_MHLA_DBG"):      # probe build: work-skipping switches (wrong results, timing only)
-    pkg._abi.LIB_PATH = os.path.join(os.path.dirname(pkg._abi.LIB_PATH), "libfavit_probe.so")
+    pkg._abi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_build", "libfavit_probe.so")
 K = pkg.kernels
 B, L, H, hd, W = 256, 197, 6, 64, 7
 D = H * hd

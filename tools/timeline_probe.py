@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 pkg = importlib.import_module("focused-attention-vit_amd")
-pkg._abi.LIB_PATH = os.path.join(os.path.dirname(pkg._abi.LIB_PATH), "libfavit_probe.so")
+pkg._abi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_build", "libfavit_probe.so")
 K, A = pkg.kernels, pkg._abi
 lib = A.lib()
 lib.favit_probe_buffer.argtypes = [ctypes.c_void_p]
