@@ -66,9 +66,11 @@ _SIGS = {
     "favit_layernorm_bwd": ([vp, C.c_int, vp, i64, vp, vp, vp, vp, vp, i64, vp, C.c_int, vp, vp, i32, vp, vp, i32,
                              i64, i32, f32, u64, vp], C.c_int),
     "favit_reduce_rows": ([vp, i64, vp, i64, i32, i32, vp], C.c_int),
+    "favit_reduce_rows_multi": ([i32, vp, vp, vp, i64, i32, vp], C.c_int),
     "favit_mhla_fold_fwd": ([vp, vp, vp, vp, vp, C.c_int, vp, vp, i32, i32, vp], C.c_int),
     "favit_mhla_fold_fwd_multi": ([i32, vp, vp, vp, vp, vp, C.c_int, vp, i32, i32, vp], C.c_int),
     "favit_mhla_fold_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], C.c_int),
+    "favit_mhla_fold_bwd_multi": ([i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp], C.c_int),
     "favit_mhla_attn_fwd": ([vp, vp, vp, i32, i32, i32, i32, i32, C.c_int, f32, u64, vp], C.c_int),
     "favit_mhla_attn_bwd": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, C.c_int, f32, u64, vp], C.c_int),
     "favit_sdpa_fwd": ([C.POINTER(SdpaDesc), vp], C.c_int),

@@ -1473,6 +1473,35 @@ __global__ __launch_bounds__(256) void fold_bwd_all_kernel(const float* __restri
   }
 }
 
+// The backward folds of up to FOLD_BWD_MAX layers in ONE launch (blockIdx.y = layer): each is ~100 small
+// workgroups and latency-bound (22.9 us x 12 per cfg2 step as separate launches), the gradients they produce
+// (qkv.{weight,bias}, latent_proj.{weight,bias}) feed nothing in the backward chain.  Accumulating form only.
+constexpr int FOLD_BWD_MAX = 16;
+struct FoldBwdBatch {
+  const float* dweff[FOLD_BWD_MAX];
+  const float* dbeff[FOLD_BWD_MAX];
+  const float* wqkv[FOLD_BWD_MAX];
+  const float* bqkv[FOLD_BWD_MAX];
+  const float* wl[FOLD_BWD_MAX];
+  float* dwqkv[FOLD_BWD_MAX];
+  float* dbqkv[FOLD_BWD_MAX];
+  float* dwl[FOLD_BWD_MAX];
+  float* dbl[FOLD_BWD_MAX];
+};
+template <int HD>
+__global__ __launch_bounds__(256) void fold_bwd_multi_kernel(FoldBwdBatch fb, int D, int H, int gwx, int nw, int glx) {
+  constexpr int SW = HD * HD + HD * FOLD_TC, SL = 2 * 64 * (HD + 1);
+  __shared__ __attribute__((aligned(16))) float smem[SW > SL ? SW : SL];
+  const int b = blockIdx.x, z = blockIdx.y;
+  if (b < nw) {
+    fold_w_body<float, HD, true>(fb.dweff[z], fb.dbeff[z], fb.wl[z], nullptr, fb.dwqkv[z], nullptr, fb.dbqkv[z], D, H, 1,
+                                 b % gwx, b / gwx, smem);
+  } else {
+    const int r = b - nw;
+    fold_bwd_l_body<HD>(fb.dweff[z], fb.dbeff[z], fb.wqkv[z], fb.bqkv[z], fb.dwl[z], fb.dbl[z], D, r % glx, r / glx, smem);
+  }
+}
+
 // Forward folds of up to FOLD_MAX independent blocks (the layers of one encoder) in ONE launch:
 // the fold only depends on parameters, so all of them can run before the first block.
 constexpr int FOLD_MAX = 32;
@@ -1722,6 +1751,36 @@ extern "C" int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const
     case 16: hipLaunchKernelGGL(fold_bwd_all_kernel<16>, grid, dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, wl, dwqkv, dbqkv, dwl, dbl, D, H, accumulate, gwx, nw, glx); break;
     case 32: hipLaunchKernelGGL(fold_bwd_all_kernel<32>, grid, dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, wl, dwqkv, dbqkv, dwl, dbl, D, H, accumulate, gwx, nw, glx); break;
     case 64: hipLaunchKernelGGL(fold_bwd_all_kernel<64>, grid, dim3(256), 0, st, dweff, dbeff, wqkv, bqkv, wl, dwqkv, dbqkv, dwl, dbl, D, H, accumulate, gwx, nw, glx); break;
+    default: return FAVIT_ERR_UNSUPPORTED;
+  }
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_mhla_fold_bwd_multi(int32_t n, const float* const* dweff, const float* const* dbeff,
+                                         const float* const* wqkv, const float* const* bqkv, const float* const* wl,
+                                         float* const* dwqkv, float* const* dbqkv, float* const* dwl, float* const* dbl,
+                                         int32_t D, int32_t H, void* stream) {
+  if (n <= 0 || n > FOLD_BWD_MAX || !dweff || !dbeff || !wqkv || !bqkv || !wl || !dwqkv || !dbqkv || !dwl || !dbl ||
+      D <= 0 || H <= 0 || D % H)
+    return FAVIT_ERR_INVALID;
+  FoldBwdBatch fb;
+  for (int i = 0; i < n; ++i) {
+    if (!dweff[i] || !dbeff[i] || !wqkv[i] || !bqkv[i] || !wl[i] || !dwqkv[i] || !dbqkv[i] || !dwl[i] || !dbl[i])
+      return FAVIT_ERR_INVALID;
+    fb.dweff[i] = dweff[i]; fb.dbeff[i] = dbeff[i]; fb.wqkv[i] = wqkv[i]; fb.bqkv[i] = bqkv[i]; fb.wl[i] = wl[i];
+    fb.dwqkv[i] = dwqkv[i]; fb.dbqkv[i] = dbqkv[i]; fb.dwl[i] = dwl[i]; fb.dbl[i] = dbl[i];
+  }
+  const int hd = D / H;
+  const int gwx = (D + 1 + FOLD_TC - 1) / FOLD_TC, gwy = 2 * H + (D + hd - 1) / hd;      // fold_w grid
+  const int glx = 2 * H, gly = (D + 64) / 64;                                             // fold_bwd_l grid
+  const int nw = gwx * gwy;
+  const dim3 grid((unsigned)(nw + glx * gly), (unsigned)n);
+  hipStream_t st = as_stream(stream);
+  switch (hd) {
+    case 16: hipLaunchKernelGGL(fold_bwd_multi_kernel<16>, grid, dim3(256), 0, st, fb, D, H, gwx, nw, glx); break;
+    case 32: hipLaunchKernelGGL(fold_bwd_multi_kernel<32>, grid, dim3(256), 0, st, fb, D, H, gwx, nw, glx); break;
+    case 64: hipLaunchKernelGGL(fold_bwd_multi_kernel<64>, grid, dim3(256), 0, st, fb, D, H, gwx, nw, glx); break;
     default: return FAVIT_ERR_UNSUPPORTED;
   }
   FAVIT_CHECK_LAUNCH();

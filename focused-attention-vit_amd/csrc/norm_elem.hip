@@ -194,6 +194,45 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restri
   }
 }
 
+// Several stacked-pair reductions in ONE launch (the dgamma / dbeta partials of up to REDUCE_MULTI_MAX LayerNorm
+// backward passes: 24 launches of ~5 us per cfg2 step otherwise).  Entry e: in [2][rows][cols] -> out0, out1 [cols],
+// ADDED to the destinations (rows split over gridDim.z / n blocks, fp32 atomics as in the single form).
+constexpr int REDUCE_MULTI_MAX = 32;
+struct ReduceMulti {
+  const float* in[REDUCE_MULTI_MAX];
+  float* out0[REDUCE_MULTI_MAX];
+  float* out1[REDUCE_MULTI_MAX];
+};
+__global__ __launch_bounds__(1024) void reduce_rows_multi_kernel(ReduceMulti rm, long rows, int cols, int zsplit) {
+  __shared__ float red[16][64];
+  const int e = blockIdx.z / zsplit, z = blockIdx.z % zsplit;
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const float* src = rm.in[e] + (long)blockIdx.y * rows * cols;
+  float* dst = blockIdx.y ? rm.out1[e] : rm.out0[e];
+  const long per = (rows + zsplit - 1) / zsplit;
+  const long rbeg = (long)z * per, rend = min(rows, rbeg + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < cols) {
+    long r = rbeg + ry;
+    for (; r + 48 < rend; r += 64) {
+      s0 += src[r * cols + col];
+      s1 += src[(r + 16) * cols + col];
+      s2 += src[(r + 32) * cols + col];
+      s3 += src[(r + 48) * cols + col];
+    }
+    for (; r < rend; r += 16) s0 += src[r * cols + col];
+  }
+  red[ry][cx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ry == 0 && col < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cx];
+    atomicAdd(dst + col, t);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 template <typename S, typename T>
 __global__ void cast_kernel(const S* __restrict__ src, T* __restrict__ dst, long n) {
@@ -474,6 +513,21 @@ extern "C" int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_
   if (!in || !out || rows <= 0 || cols <= 0) return FAVIT_ERR_INVALID;
   hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 63) / 64, 1), dim3(1024), 0, as_stream(stream), in, (long)ld, out,
                      (float*)nullptr, (long)rows, cols, accumulate);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_reduce_rows_multi(int32_t n, const float* const* in, float* const* out0, float* const* out1,
+                                       int64_t rows, int32_t cols, void* stream) {
+  if (n <= 0 || n > REDUCE_MULTI_MAX || !in || !out0 || !out1 || rows <= 0 || cols <= 0) return FAVIT_ERR_INVALID;
+  ReduceMulti rm;
+  for (int i = 0; i < n; ++i) {
+    if (!in[i] || !out0[i] || !out1[i]) return FAVIT_ERR_INVALID;
+    rm.in[i] = in[i]; rm.out0[i] = out0[i]; rm.out1[i] = out1[i];
+  }
+  const int zsplit = rows >= 512 ? 8 : 1;
+  hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3((cols + 63) / 64, 2, (unsigned)(n * zsplit)), dim3(1024), 0,
+                     as_stream(stream), rm, (long)rows, cols, zsplit);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }

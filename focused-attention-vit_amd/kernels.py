@@ -248,11 +248,13 @@ def layernorm_fwd(x, ldx, gamma, beta, rows, D, out_dtype, eps=1e-5):
 
 
 def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None, lddx=None, want_lp=False,
-                  dg_out=None, db_out=None, lp_drop=(0.0, 0)):
+                  dg_out=None, db_out=None, lp_drop=(0.0, 0), defer=None):
     """Returns dx (fp32, row stride lddx), dx_lp (dy.dtype copy or None), dgamma, dbeta.
     dg_out / db_out: optional fp32 [D] gradient buffers the affine gradients are ACCUMULATED into
     (then None is returned in their place).  lp_drop = (p, seed): dx_lp carries that dropout mask (the branch it
-    feeds had its output dropped in forward), saving a separate masking pass."""
+    feeds had its output dropped in forward), saving a separate masking pass.
+    defer (a list, with dg_out / db_out): the fold of the partial sums into dg_out / db_out is NOT launched; the
+    entry (part, dg_out, db_out) is appended and the caller folds several of them in one launch (reduce_rows_multi)."""
     require_gpu(dy, x)
     dev = x.device
     if dx is None:
@@ -262,7 +264,10 @@ def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None,
     nparts = int(min(2048, (rows + 3) // 4))
     part = torch.empty((2, nparts, D), dtype=torch.float32, device=dev)
     acc = dg_out is not None and db_out is not None
-    if acc:
+    if acc and defer is not None:
+        defer.append((part, dg_out, db_out))
+        dg = db = None
+    elif acc:
         dg, db = dg_out, db_out
     else:
         dgb = torch.empty((2, D), dtype=torch.float32, device=dev)
@@ -297,6 +302,24 @@ def gemm_residual_ln(a, w, bias, residual, gamma, beta, eps=1e-5):
         return None
     _abi.check(rc, "favit_gemm_residual_ln")
     return x_out, xn, mean, rstd
+
+
+def reduce_rows_multi(entries):
+    """entries: [(part [2, rows, cols] fp32 contiguous, out0 [cols], out1 [cols])] -> out0 += colsum(part[0]),
+    out1 += colsum(part[1]) for every entry in ONE launch (at most 32 entries per launch)."""
+    for i in range(0, len(entries), 32):
+        chunk = entries[i:i + 32]
+        n = len(chunk)
+        rows, cols = chunk[0][0].shape[1], chunk[0][0].shape[2]
+        arr = C.c_void_p * n
+        for part, o0, o1 in chunk:
+            require_gpu(part, o0, o1)
+            if tuple(part.shape) != (2, rows, cols) or not part.is_contiguous() or part.dtype != torch.float32:
+                raise ValueError("reduce_rows_multi: every entry must be a contiguous fp32 [2, rows, cols] stack of one shape")
+        _abi.check(_abi.lib().favit_reduce_rows_multi(n, arr(*[e[0].data_ptr() for e in chunk]),
+                                                      arr(*[e[1].data_ptr() for e in chunk]),
+                                                      arr(*[e[2].data_ptr() for e in chunk]), rows, cols, _st()),
+                   "favit_reduce_rows_multi")
 
 
 def reduce_rows(t2d: torch.Tensor) -> torch.Tensor:
@@ -351,6 +374,24 @@ def mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H, out=None):
     _abi.check(_abi.lib().favit_mhla_fold_bwd(_p(dweff), _p(dbeff), _p(wqkv), _p(bqkv), _p(wl), _p(dwqkv), _p(dbqkv),
                                               _p(dwl), _p(dbl), D, H, int(acc), _st()), "favit_mhla_fold_bwd")
     return dwqkv, dbqkv, dwl, dbl
+
+
+def mhla_fold_bwd_multi(entries, H):
+    """entries: [(dweff, dbeff, wqkv, bqkv, wl, (dwqkv, dbqkv, dwl, dbl))] of equal geometry: every layer's fold
+    backward in ONE launch (chunks of 16), ACCUMULATING into the gradient buffers."""
+    for i in range(0, len(entries), 16):
+        chunk = entries[i:i + 16]
+        n = len(chunk)
+        D = chunk[0][2].shape[1]
+        arr = C.c_void_p * n
+        cols = []
+        for j in range(5):
+            cols.append(arr(*[e[j].data_ptr() for e in chunk]))
+        for j in range(4):
+            cols.append(arr(*[e[5][j].data_ptr() for e in chunk]))
+        for e in chunk:
+            require_gpu(*e[:5], *e[5])
+        _abi.check(_abi.lib().favit_mhla_fold_bwd_multi(n, *cols, D, H, _st()), "favit_mhla_fold_bwd_multi")
 
 
 def mhla_attn_fwd(qkv, B, L, H, hd, W, mask=None, p=0.0, seed=0):

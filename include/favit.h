@@ -181,6 +181,11 @@ int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x, int64_t ld
 /* out[c] (+)= sum_r in[r*ld + c] */
 int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t accumulate,
                       void* stream);
+/* n (<= 32) stacked-pair reductions in ONE launch: entry e adds the column sums of in[e] ([2][rows][cols], contiguous)
+ * to out0[e] / out1[e] ([cols] each).  Used for the dgamma / dbeta partials of several favit_layernorm_bwd calls
+ * (each called with dgamma = NULL): the arguments are HOST arrays of n device pointers. */
+int favit_reduce_rows_multi(int32_t n, const float* const* in, float* const* out0, float* const* out1, int64_t rows,
+                            int32_t cols, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * MHLA (models/mhla.py).  latent_proj (mhla.py:41,105-106) is one Linear(hd,hd) shared
@@ -202,6 +207,12 @@ int favit_mhla_fold_fwd_multi(int32_t n, const float* const* wqkv, const float* 
 int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const float* wqkv, const float* bqkv,
                         const float* wl, float* dwqkv, float* dbqkv, float* dwl, float* dbl, int32_t D, int32_t H,
                         int32_t accumulate, void* stream);
+/* The backward fold of n (<= 16) layers in ONE launch, always ACCUMULATING into the gradient buffers (HOST arrays of n
+ * device pointers, as favit_mhla_fold_fwd_multi). */
+int favit_mhla_fold_bwd_multi(int32_t n, const float* const* dweff, const float* const* dbeff, const float* const* wqkv,
+                              const float* const* bqkv, const float* const* wl, float* const* dwqkv,
+                              float* const* dbqkv, float* const* dwl, float* const* dbl, int32_t D, int32_t H,
+                              void* stream);
 
 /* Windowed attention core: window index rule (mhla.py:46-83, closed form in-kernel, the
  * duplicated pad indices take part in the softmax), gather (117-126, never materialised),
