@@ -392,7 +392,10 @@ _DEFER = {"on": False, "fold": [], "ln": [], "every": 4, "blocks": 0}
 
 
 def begin_deferred() -> None:
-    _DEFER.update(on=not _SIDE["enabled"], fold=[], ln=[], blocks=0)
+    # single process: one batch at the end of the encoder backward; under data parallelism every 4 blocks, so that
+    # the buckets holding these gradients start their all-reduce while the rest of backward still runs
+    _DEFER.update(on=not _SIDE["enabled"], fold=[], ln=[], blocks=0,
+                  every=4 if _STATE["grad_ready"] is not None else 1 << 30)
 
 
 def flush_deferred(force: bool = True) -> None:
@@ -423,6 +426,31 @@ def end_deferred() -> None:
     _DEFER["on"] = False
 
 
+# Zero-initialised fp32 vectors for fused column sums that have no gradient buffer to accumulate into (the bias
+# gradient of the folded qkv weights, one per block): carved out of ONE zero-filled pool per encoder backward instead
+# of one 5-us fill launch each (12 per cfg2 step).
+_ZPOOL = {"buf": None, "off": 0}
+
+
+def begin_zero_pool(n_floats: int, device) -> None:
+    _ZPOOL["buf"] = torch.zeros(n_floats, dtype=torch.float32, device=device) if n_floats > 0 else None
+    _ZPOOL["off"] = 0
+
+
+def end_zero_pool() -> None:
+    _ZPOOL["buf"] = None
+
+
+def _zero_vec(n: int, device) -> torch.Tensor:
+    buf = _ZPOOL["buf"]
+    n4 = (n + 3) // 4 * 4                               # keep every slice 16-byte aligned (slab reduction)
+    if buf is not None and buf.device == device and _ZPOOL["off"] + n4 <= buf.numel():
+        o = _ZPOOL["off"]
+        _ZPOOL["off"] = o + n4
+        return buf[o:o + n]
+    return torch.zeros(n, dtype=torch.float32, device=device)
+
+
 def lin_bwd_w(dy, a, M, N, Kd, want_bias=True, wp=None, bp=None, allow_fp8=True):
     """dw[N,K] = dy[M,N]^T @ a[M,K] (fp32, split-K over the tokens), db[N] = column sums of dy (fused).
     If the parameters wp / bp own usable .grad buffers the results are accumulated there and None
@@ -436,7 +464,7 @@ def lin_bwd_w(dy, a, M, N, Kd, want_bias=True, wp=None, bp=None, allow_fp8=True)
     dw = tw if tw is not None else torch.empty((N, Kd), dtype=torch.float32, device=dy.device)
     db = None
     if want_bias:
-        db = tb if tb is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
+        db = tb if tb is not None else _zero_vec(N, dy.device)
     if _WG["list"] is not None and dy.dtype == torch.bfloat16:
         # deferred: joins the block's grouped weight-gradient launch
         _WG["list"].append((dy, a, dw, db, tw is not None,
@@ -878,6 +906,7 @@ class EncoderOp:
         grads = []
         begin_wgrads()
         begin_deferred()
+        begin_zero_pool(sum(3 * D + 4 for bs in self.blocks if isinstance(bs.attn, MHLAChain)), dy.device)
 
         def ln_bwd(dxn, xin, gam, bet, mu, rs, dres, pd):
             """LayerNorm backward of the stream; the dgamma / dbeta fold joins the deferred batch when the parameters own
@@ -920,9 +949,11 @@ class EncoderOp:
             _WG["list"] = None                # drop the half-collected weight gradients of the failed backward
             _SIDE["pending"].clear()
             _DEFER.update(on=False, fold=[], ln=[])
+            end_zero_pool()
             raise
         end_wgrads()
         end_deferred()
+        end_zero_pool()
         join_side_stream()
         return [g.reshape(B, L, D)], grads
 

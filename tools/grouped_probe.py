@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 pkg = importlib.import_module("focused-attention-vit_amd")
 if os.environ.get("FAVIT_GEMM_DBG"):
-    pkg._abi.LIB_PATH = os.path.join(os.path.dirname(pkg._abi.LIB_PATH), "libfavit_probe.so")
+    pkg._abi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_build", "libfavit_probe.so")
 K = pkg.kernels
 dev = "cuda"
 for name, T, D in (("cfg2 Small", 256 * 197, 384), ("cfg4 Base", 64 * 577, 768)):
