@@ -69,7 +69,6 @@ struct KParams {
   int store_policy;    // cache policy of the epilogue's output stores (store16_policy)
   int rowsum_store;    // 1: a_rowsum is a private slab slot of this split (plain store), 0: atomicAdd
   int q_block0, q_tile0;   // p4: blocks >= q_block0 (> 0) run 64x128 quarter tiles of the full tiles from q_tile0 on
-  int lite_ok;             // p4, weight-gradient layout: waves 4-7 of a tile whose rows 128..255 lie past M idle
 #ifdef FAVIT_PROBE
   int dbg;     // probe build only (make probe; tools/): 1 = skip epilogue, 2 = skip main loop
   unsigned long long* probe;   // probe build only: per-wave cycle stamps of the pp kernel (favit_probe_buffer)
@@ -951,13 +950,6 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // Weight-gradient tiles whose rows 128..255 lie past M (dW of a 384-row weight: every second row tile; 18 of the
-  // 63 tiles of a ViT-Small block's grouped launch): waves 4-7 own exactly that half -- its two A sub-image pieces per
-  // stage and the MFMAs of rows 128..255 -- so they issue only their B piece, skip fragment reads, MFMAs and the
-  // epilogue, and keep the barriers.  A third less operand traffic and half the matrix work for such a tile; the
-  // co-resident workgroup gets the CU's DMA and MFMA slots.
-  bool lite = false;
-  if constexpr (!AK && !BKM) lite = p.lite_ok && (m0 + 128 >= p.M) && wave >= 4;
   // 3 pieces per wave per stage: 2 of A (16 pieces), 1 of B (8 pieces)
   const char* sa[2];
   const char* sb;
@@ -993,12 +985,10 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
   const long b_step = BKM ? 64 : (long)P4_BK * p.ldb * 2;
   auto issue = [&](int buf) {
     char* st = smem + buf * P4_STAGE;
-    if (!lite) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + da[j]), 16, 0, 0);
-        sa[j] += a_step;
-      }
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + da[j]), 16, 0, 0);
+      sa[j] += a_step;
     }
     __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + db), 16, 0, 0);
     sb += b_step;
@@ -1008,14 +998,10 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
   if (nk > 1) issue(1);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // all but the youngest stage's loads of THIS wave have landed: 3 loads per stage (1 for a lite wave)
-    if (kt + 1 < nk) {
-      if (lite) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);
-    if (lite) { cur = cur == 2 ? 0 : cur + 1; continue; }
     const char* st = smem + cur * P4_STAGE;
     const char* la = AK ? st : st + (wr >> 1) * (P4_A_BYTES / 2);
     const int ra = AK ? wr * 64 : (wr & 1) * 64;
@@ -1078,7 +1064,6 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
 #ifdef FAVIT_PROBE
   if (tl) tl1 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (lite) return;       // rows 128..255 of this tile do not exist (no barrier below)
   wave_epilogue<bf16_t, OutT>(p, acc, C, m0 + wr * 64, n0 + wc * 64, lane,
                               reinterpret_cast<float*>(smem + wave * WEPI_BYTES), split == 0, alpha);
 #ifdef FAVIT_PROBE
@@ -2104,7 +2089,7 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 // same result; the work-skipping probe switch (FAVIT_GEMM_DBG) exists only in the `make probe` build.
 struct GemmKnobs {
   int dbg, store_policy;
-  bool force128, no_p4, no_p7, no_s64, no_pp, no_quarter, no_lite;
+  bool force128, no_p4, no_p7, no_s64, no_pp, no_quarter;
   long quarter_max;
   GemmKnobs() {
     const char* e;
@@ -2120,7 +2105,6 @@ struct GemmKnobs {
     no_s64 = getenv("FAVIT_GEMM_NO_S64") != nullptr;
     no_pp = getenv("FAVIT_GEMM_NO_PP") != nullptr;
     no_quarter = getenv("FAVIT_GEMM_NO_QUARTER") != nullptr;
-    no_lite = getenv("FAVIT_GEMM_NO_LITE") != nullptr;
     quarter_max = (e = getenv("FAVIT_GEMM_QUARTER_MAX")) ? atol(e) : 128;       // tail rounds up to 25 % of the slots
   }
 };
@@ -2226,7 +2210,6 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.xcd_split = 0;
   kp.q_block0 = 0;
   kp.q_tile0 = 0;
-  kp.lite_ok = knobs().no_lite ? 0 : 1;
   kp.alpha = g->alpha;
   kp.scale_a = fp8 ? g->scale_a : nullptr;
   kp.scale_b = fp8 ? g->scale_b : nullptr;
@@ -2481,7 +2464,6 @@ int grouped_tn_impl(const favit_gemm_t* gs, int32_t count, float* ws, int64_t ws
     kp.store_policy = 0;
     kp.rowsum_store = 0;
     kp.q_block0 = kp.q_tile0 = 0;
-    kp.lite_ok = knobs().no_lite ? 0 : 1;
     kp.scale_a = kp.scale_b = nullptr;
 #ifdef FAVIT_PROBE
     kp.dbg = knobs().dbg;            // probe build: FAVIT_GEMM_DBG=1 times the grouped main loop without its epilogue
