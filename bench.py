@@ -169,7 +169,33 @@ def cpu_baseline(cfg, model, segs_np):
 def main():
     if os.environ.get("FAVIT_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["FAVIT_BENCH_WATCHDOG"]), exit=True)
+        import threading
+        limit = int(os.environ["FAVIT_BENCH_WATCHDOG"])
+        faulthandler.dump_traceback_later(limit, exit=True)
+
+        def native_threads():
+            # faulthandler only sees Python threads; the collective backends' workers are native.  Shortly before the
+            # limit, record every OS thread of this process: name, scheduler state and the kernel wait channel
+            # (futex = parked on a condition / HIP signal, poll / recv = network, running = spinning).
+            time.sleep(max(1, limit - 5))
+            out = os.path.join(ROOT, "gpurun_out", f"hang_rank{os.environ.get('RANK', '0')}.txt")
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            with open(out, "w") as f:
+                for tid in sorted(os.listdir("/proc/self/task"), key=int):
+                    rec = [tid]
+                    for name in ("comm", "wchan", "syscall"):
+                        try:
+                            with open(f"/proc/self/task/{tid}/{name}") as g:
+                                rec.append(g.read().strip()[:60])
+                        except OSError as e:
+                            rec.append(f"<{e.errno}>")
+                    try:
+                        with open(f"/proc/self/task/{tid}/stat") as g:
+                            rec.append(g.read().rsplit(")", 1)[1].split()[0])
+                    except OSError:
+                        rec.append("?")
+                    f.write("\t".join(rec) + "\n")
+        threading.Thread(target=native_threads, daemon=True).start()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

@@ -108,6 +108,14 @@ __device__ __forceinline__ uint32_t favit_rand_u32(uint64_t seed, uint64_t idx) 
   x ^= x >> 16;
   return x;
 }
+// Dropout epoch (favit_set_dropout_epoch, include/favit.h): a device word every dropout-drawing kernel mixes into its
+// by-value seed, so that a step captured ONCE in a HIP graph (seeds frozen into the kernel arguments) still draws
+// fresh masks at every replay -- the graph's first node increments the word.  NULL (the default): seeds as given.
+// Forward and backward kernels of one replay read the same value, so recomputed masks stay consistent.
+extern "C" const unsigned long long* favit_dropout_epoch_ptr_(void);
+__device__ __forceinline__ uint64_t favit_eff_seed(uint64_t seed, const unsigned long long* epoch) {
+  return epoch ? seed + (uint64_t)(*epoch) * 0x9E3779B97F4A7C15ull : seed;
+}
 // keep with probability 1-p
 __device__ __forceinline__ bool favit_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
   return favit_rand_u32(seed, idx) >= thresh;

@@ -64,6 +64,7 @@ struct KParams {
   uint32_t drop_thresh;
   float drop_scale;
   uint64_t drop_seed;
+  const unsigned long long* drop_epoch;   // favit_set_dropout_epoch word (or null): mixed into drop_seed in the kernel
   int ntiles;          // output tiles per (split, batch)
   int xcd_split;       // 1: 1-D grid of ntiles*nsplit blocks, all tiles of a split on one XCD
   int store_policy;    // cache policy of the epilogue's output stores (store16_policy)
@@ -313,7 +314,7 @@ __device__ __forceinline__ void run_epilogue(const KParams& p, const float* epi,
       if (p.drop_thresh) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          a[j] = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n + j), p.drop_thresh) ? a[j] * p.drop_scale : 0.f;
+          a[j] = favit_keep(favit_eff_seed(p.drop_seed, p.drop_epoch), (uint64_t)(m * p.N + n + j), p.drop_thresh) ? a[j] * p.drop_scale : 0.f;
       }
       if (p.residual) {
         const float4 r = *reinterpret_cast<const float4*>(p.residual + m * p.ld_res + n);
@@ -346,7 +347,7 @@ __device__ __forceinline__ void run_epilogue(const KParams& p, const float* epi,
       else if (p.act == FAVIT_ACT_MULAUX)
         v *= to_f32(reinterpret_cast<const InT*>(p.aux_in)[m * p.ld_aux_in + n]);
       if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n] = from_f32<OutT>(vx);
-      if (p.drop_thresh) v = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n), p.drop_thresh) ? v * p.drop_scale : 0.f;
+      if (p.drop_thresh) v = favit_keep(favit_eff_seed(p.drop_seed, p.drop_epoch), (uint64_t)(m * p.N + n), p.drop_thresh) ? v * p.drop_scale : 0.f;
       if (first_split && p.residual) v += p.residual[m * p.ld_res + n];
       if (p.atomic) {
         if constexpr (sizeof(OutT) == 4) atomicAdd(reinterpret_cast<float*>(C) + m * p.ldc + n, v);
@@ -823,7 +824,7 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
         if (p.drop_thresh) {
 #pragma unroll
           for (int c = 0; c < CPL; ++c)
-            a[c] = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n + c), p.drop_thresh) ? a[c] * p.drop_scale : 0.f;
+            a[c] = favit_keep(favit_eff_seed(p.drop_seed, p.drop_epoch), (uint64_t)(m * p.N + n + c), p.drop_thresh) ? a[c] * p.drop_scale : 0.f;
         }
         if (p.residual) {
 #pragma unroll
@@ -855,7 +856,7 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
           else if (p.act == FAVIT_ACT_MULAUX)
             v *= to_f32(reinterpret_cast<const InT*>(p.aux_in)[m * p.ld_aux_in + n + c]);
           if (p.aux_out) reinterpret_cast<OutT*>(p.aux_out)[m * p.ld_aux_out + n + c] = from_f32<OutT>(vx);
-          if (p.drop_thresh) v = favit_keep(p.drop_seed, (uint64_t)(m * p.N + n + c), p.drop_thresh) ? v * p.drop_scale : 0.f;
+          if (p.drop_thresh) v = favit_keep(favit_eff_seed(p.drop_seed, p.drop_epoch), (uint64_t)(m * p.N + n + c), p.drop_thresh) ? v * p.drop_scale : 0.f;
           if (p.residual) v += p.residual[m * p.ld_res + n + c];
           C[m * p.ldc + n + c] = from_f32<OutT>(v);
         }
@@ -2225,6 +2226,7 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.drop_thresh = dropout_threshold(g->dropout_p);
   kp.drop_scale = 1.0f / (1.0f - g->dropout_p);
   kp.drop_seed = g->dropout_seed;
+  kp.drop_epoch = favit_dropout_epoch_ptr_();
   if (kp.drop_thresh && (splits > 1 || batch != 1)) return FAVIT_ERR_UNSUPPORTED;
 
   const int in_vec = fp8 ? 16 : (g->in_dtype == FAVIT_BF16 ? 8 : 4);   // elements per 16-B load
@@ -2460,7 +2462,7 @@ int grouped_tn_impl(const favit_gemm_t* gs, int32_t count, float* ws, int64_t ws
     kp.ntiles = (int)(((g->M + P4_BM - 1) / P4_BM) * kp.tiles_n);
     kp.xcd_split = 1;
     kp.alpha = 1.0f;
-    kp.drop_thresh = 0; kp.drop_scale = 1.0f; kp.drop_seed = 0;
+    kp.drop_thresh = 0; kp.drop_scale = 1.0f; kp.drop_seed = 0; kp.drop_epoch = nullptr;
     kp.store_policy = 0;
     kp.rowsum_store = 0;
     kp.q_block0 = kp.q_tile0 = 0;

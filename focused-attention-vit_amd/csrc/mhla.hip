@@ -266,6 +266,7 @@ struct AttnArgs {
   uint32_t thresh;
   float keep_scale;
   uint64_t seed;
+  const unsigned long long* epoch;   // favit_set_dropout_epoch word (or null)
 };
 
 // scores + softmax of one query row (8 lanes own the row; every lane ends with all p[w])
@@ -305,6 +306,7 @@ constexpr int FWD_QPB = 64;   // query rows per workgroup (forward)
 
 template <typename T, int DPL, int WMAX>
 __global__ __launch_bounds__(256) void mhla_fwd_kernel(AttnArgs a) {
+  if (a.thresh) a.seed = favit_eff_seed(a.seed, a.epoch);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HD = 8 * DPL;
   const int tid = threadIdx.x, lane8 = tid & 7, qs = tid >> 3;
@@ -362,6 +364,7 @@ __global__ __launch_bounds__(256) void mhla_fwd_kernel(AttnArgs a) {
 
 template <typename T, int DPL, int WMAX>
 __global__ __launch_bounds__(256) void mhla_bwd_kernel(AttnArgs a) {
+  if (a.thresh) a.seed = favit_eff_seed(a.seed, a.epoch);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int HD = 8 * DPL;
   const int tid = threadIdx.x, lane8 = tid & 7, qs = tid >> 3;
@@ -573,6 +576,7 @@ __device__ __forceinline__ void store_rows16(bf16_t* row, const f32x4 (&o)[HD / 
 
 template <int HD, bool PLAIN>            // PLAIN: no mask, no dropout (compiled out)
 __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
+  if (a.thresh) a.seed = favit_eff_seed(a.seed, a.epoch);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = HD * 2 + 16;                      // padded row: conflict-free fragment reads
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -710,6 +714,7 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------
 template <int HD>
 __global__ __launch_bounds__(256) void mhla_bwd_mfma_kernel(AttnArgs a) {
+  if (a.thresh) a.seed = favit_eff_seed(a.seed, a.epoch);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = HD * 2 + 16;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -975,6 +980,7 @@ __global__ __launch_bounds__(256) void mhla_bwd_mfma_kernel(AttnArgs a) {
 // dropout draws are compiled out.
 template <int HD, bool PLAIN>
 __global__ __launch_bounds__(256) void mhla_bwd_mfma2_kernel(AttnArgs a) {
+  if (a.thresh) a.seed = favit_eff_seed(a.seed, a.epoch);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RS = HD * 2 + 16;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -1608,6 +1614,7 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
   a.thresh = dropout_threshold(p);
   a.keep_scale = 1.0f / (1.0f - p);
   a.seed = seed;
+  a.epoch = favit_dropout_epoch_ptr_();
   hipStream_t st = as_stream(stream);
   if (!bwd && dtype == FAVIT_BF16 && (hd == 32 || hd == 64 || hd == 128) && getenv("FAVIT_MHLA_VALU") == nullptr) {
     const int h = W / 2;

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy,
                                                      long lddx, LpT* __restrict__ dx_lp,
                                                      float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
                                                      long rows, int D, uint32_t lp_thresh, float lp_scale,
-                                                     uint64_t lp_seed) {
+                                                     uint64_t lp_seed, const unsigned long long* lp_epoch) {
+  if (lp_thresh) lp_seed = favit_eff_seed(lp_seed, lp_epoch);
   __shared__ float red[4][2][256 * NV > 2048 ? 2048 : 256 * NV];   // [wave][gamma|beta][D padded]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D >> 2;
@@ -247,7 +248,8 @@ __global__ void cast_kernel(const S* __restrict__ src, T* __restrict__ dst, long
 
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n, uint32_t thresh, float scale,
-                               uint64_t seed) {
+                               uint64_t seed, const unsigned long long* epoch) {
+  seed = favit_eff_seed(seed, epoch);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = favit_keep(seed, (uint64_t)i, thresh) ? from_f32<T>(to_f32(x[i]) * scale) : from_f32<T>(0.f);
 }
@@ -530,11 +532,11 @@ extern "C" int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x,
   if (dy_dtype == FAVIT_F32)                                                                                       \
     hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, dim3(256), 0, st, (const float*)dy, x, (long)ldx,  \
                        gamma, mean, rstd, dres, dx, (long)lddx, (float*)dx_lp, dgamma_part, dbeta_part, (long)rows, \
-                       D, lp_thresh, lp_scale, lp_dropout_seed);                                                                                    \
+                       D, lp_thresh, lp_scale, lp_dropout_seed, favit_dropout_epoch_ptr_());                                                        \
   else                                                                                                             \
     hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t, NV>), grid, dim3(256), 0, st, (const bf16_t*)dy, x,          \
                        (long)ldx, gamma, mean, rstd, dres, dx, (long)lddx, (bf16_t*)dx_lp, dgamma_part,            \
-                       dbeta_part, (long)rows, D, lp_thresh, lp_scale, lp_dropout_seed)
+                       dbeta_part, (long)rows, D, lp_thresh, lp_scale, lp_dropout_seed, favit_dropout_epoch_ptr_())
   LN_DISPATCH_NV(D, LN_BWD);
 #undef LN_BWD
   FAVIT_CHECK_LAUNCH();
@@ -597,9 +599,9 @@ extern "C" int favit_dropout(const void* x, void* y, int dtype, int64_t n, float
   const uint32_t th = dropout_threshold(p);
   const float scale = 1.0f / (1.0f - p);
   if (dtype == FAVIT_F32)
-    hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (float*)y, (long)n, th, scale, seed);
+    hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (float*)y, (long)n, th, scale, seed, favit_dropout_epoch_ptr_());
   else if (dtype == FAVIT_BF16)
-    hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (long)n, th, scale, seed);
+    hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (long)n, th, scale, seed, favit_dropout_epoch_ptr_());
   else
     return FAVIT_ERR_INVALID;
   FAVIT_CHECK_LAUNCH();
@@ -715,6 +717,15 @@ extern "C" int favit_adamw(float* p, const float* g, float* m, float* v, void* p
 }
 
 extern "C" int favit_abi_version(void) { return FAVIT_ABI_VERSION; }
+
+// process-wide dropout epoch word (device pointer or null), read by every launcher of a dropout-drawing kernel
+static const unsigned long long* g_drop_epoch = nullptr;
+extern "C" const unsigned long long* favit_dropout_epoch_ptr_(void) { return g_drop_epoch; }
+extern "C" int favit_set_dropout_epoch(const uint64_t* device_word) {
+  if (reinterpret_cast<uintptr_t>(device_word) & 7) return FAVIT_ERR_ALIGN;
+  g_drop_epoch = reinterpret_cast<const unsigned long long*>(device_word);
+  return FAVIT_OK;
+}
 
 extern "C" const char* favit_strerror(int code) {
   switch (code) {

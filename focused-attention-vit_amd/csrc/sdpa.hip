@@ -46,6 +46,7 @@ struct SdpaArgs {
   uint32_t thresh;
   float keep_scale;
   uint64_t seed;
+  const unsigned long long* epoch;   // favit_set_dropout_epoch word (or null)
 };
 
 template <typename T> struct Mma;
@@ -175,6 +176,7 @@ __device__ __forceinline__ void tile_lstore(char* tile, int rs, const uint4 (&r)
 
 template <typename T, int NDT, int MODE>
 __global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
+  if (a.thresh) a.seed = favit_eff_seed(a.seed, a.epoch);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Mma<T> M;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -489,6 +491,7 @@ SdpaArgs base_args(const favit_sdpa_t* s) {
   a.thresh = dropout_threshold(s->dropout_p);
   a.keep_scale = 1.0f / (1.0f - s->dropout_p);
   a.seed = s->seed;
+  a.epoch = favit_dropout_epoch_ptr_();
   return a;
 }
 

@@ -11,7 +11,9 @@ template <typename PT>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, PT* __restrict__ P,
                                                           PT* __restrict__ Pd, const uint8_t* __restrict__ mask,
                                                           long m_sb, long m_sq, int H, long rows, int Lq, int Lk,
-                                                          uint32_t thresh, float keep_scale, uint64_t seed) {
+                                                          uint32_t thresh, float keep_scale, uint64_t seed,
+                                                          const unsigned long long* epoch) {
+  if (thresh) seed = favit_eff_seed(seed, epoch);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 template <typename PT, typename ST>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const PT* __restrict__ P, const float* __restrict__ dPd,
                                                           ST* __restrict__ dS, long rows, int Lk, uint32_t thresh,
-                                                          float keep_scale, uint64_t seed) {
+                                                          float keep_scale, uint64_t seed, const unsigned long long* epoch) {
+  if (thresh) seed = favit_eff_seed(seed, epoch);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long row = (long)blockIdx.x * 4 + wave;
   if (row >= rows) return;
@@ -80,10 +83,10 @@ extern "C" int favit_softmax_fwd(const float* S, void* P, void* Pd, int p_dtype,
   hipStream_t st = as_stream(stream);
   if (p_dtype == FAVIT_F32)
     hipLaunchKernelGGL((softmax_fwd_kernel<float>), grid, dim3(256), 0, st, S, (float*)P, (float*)(th ? Pd : nullptr), mask,
-                       (long)m_sb, (long)m_sq, H, rows, Lq, Lk, th, ks, seed);
+                       (long)m_sb, (long)m_sq, H, rows, Lq, Lk, th, ks, seed, favit_dropout_epoch_ptr_());
   else if (p_dtype == FAVIT_BF16)
     hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, S, (bf16_t*)P, (bf16_t*)(th ? Pd : nullptr),
-                       mask, (long)m_sb, (long)m_sq, H, rows, Lq, Lk, th, ks, seed);
+                       mask, (long)m_sb, (long)m_sq, H, rows, Lq, Lk, th, ks, seed, favit_dropout_epoch_ptr_());
   else
     return FAVIT_ERR_INVALID;
   FAVIT_CHECK_LAUNCH();
@@ -102,10 +105,10 @@ extern "C" int favit_softmax_bwd(const void* P, int p_dtype, const float* dPd, v
   hipStream_t st = as_stream(stream);
   if (p_dtype == FAVIT_F32)
     hipLaunchKernelGGL((softmax_bwd_kernel<float, float>), grid, dim3(256), 0, st, (const float*)P, dPd, (float*)dS, rows,
-                       Lk, th, ks, seed);
+                       Lk, th, ks, seed, favit_dropout_epoch_ptr_());
   else if (p_dtype == FAVIT_BF16)
     hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)P, dPd, (bf16_t*)dS,
-                       rows, Lk, th, ks, seed);
+                       rows, Lk, th, ks, seed, favit_dropout_epoch_ptr_());
   else
     return FAVIT_ERR_INVALID;
   FAVIT_CHECK_LAUNCH();

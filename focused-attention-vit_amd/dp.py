@@ -29,12 +29,25 @@ import torch.distributed as dist
 # FAVIT_DP_DEBUG=<dir>: every rank appends its sequence of bucket launches / waits to <dir>/dp_rank<r>.log
 # (collectives must be issued in the same order on every rank; this is how a mismatch is found)
 _DEBUG = os.environ.get("FAVIT_DP_DEBUG")
+# FAVIT_DP_VERIFY=1: ordering check of the overlapped path.  When a bucket's all-reduce is launched, a snapshot of the
+# slice is enqueued on the compute stream (i.e. after every kernel that wrote it, by stream order); finish() then
+# reduces the snapshots synchronously, after a full device sync, and compares with what the asynchronous collectives
+# delivered.  A collective that read its slice before the last writer had finished, or a writer that ran after the
+# launch, shows up as a mismatch (it would otherwise be a silently wrong gradient on RCCL).  Costs one extra copy and
+# one extra all-reduce per bucket: a test / bring-up switch, never on in a timed run.
+_VERIFY = bool(os.environ.get("FAVIT_DP_VERIFY"))
+# FAVIT_DP_NO_DRAIN=1: gloo only, diagnostic -- do not drain the compute stream before a host-staged collective
+_NO_DRAIN = bool(os.environ.get("FAVIT_DP_NO_DRAIN"))
 
 
 def _dbg(msg):
     r = dist.get_rank() if dist.is_initialized() else 0
     with open(os.path.join(_DEBUG, f"dp_rank{r}.log"), "a") as f:
         f.write(msg + "\n")
+
+
+def buf_is_cuda(t) -> bool:
+    return bool(t.is_cuda)
 
 
 class FlatBuffers:
@@ -160,7 +173,10 @@ class GradSync:
             if self._launched[b]:
                 raise RuntimeError(
                     f"GradSync: gradient of parameter #{i} {tuple(p.shape)} accumulated after its bucket's all-reduce "
-                    "was launched; wrap all but the last backward of a step in GradSync.no_sync() (FusedAdamW.no_sync())")
+                    "was launched.  Either a second backward of this step ran outside no_sync() -- wrap all but the "
+                    "last backward of a step in GradSync.no_sync() (FusedAdamW.no_sync()) -- or the parameter is used "
+                    "more than once in one forward (weight sharing), in which case its bucket must not go out on the "
+                    "first contribution: set GradSync.defer = True (every bucket is then launched from finish())")
             return
         self._seen[b][i] = direct
         if len(self._seen[b]) == self._pending[b]:
@@ -172,6 +188,7 @@ class GradSync:
             self._launched[b] = False
         self._seen = [dict() for _ in self.buckets]      # parameter index -> reported directly by the kernels?
         self._handles = []
+        self._snap = []
 
     def _launch(self, b):
         if self._launched[b] or not self._active:
@@ -181,7 +198,9 @@ class GradSync:
         self._launched[b] = True
         if _DEBUG:
             _dbg(f"launch sync#{id(self) % 9973} bucket {b} [{s}:{e}) thread {threading.current_thread().name}")
-        if self._host_staged and buf.is_cuda:
+        if _VERIFY:
+            self._snap.append((b, buf.clone()))
+        if self._host_staged and buf.is_cuda and not _NO_DRAIN:
             # gloo stages device tensors through pinned host memory on pool streams that its worker threads
             # synchronise.  With three or more ranks sharing ONE GPU (the only way to rehearse N ranks on a one-GPU
             # box) such an op, issued while the compute stream still has work queued, intermittently never completes
@@ -190,6 +209,37 @@ class GradSync:
             # device and is launched without any host wait.
             torch.cuda.current_stream().synchronize()
         self._handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf))
+
+    def abort(self):
+        """A backward that raised may leave asynchronous all-reduces outstanding on slices of flat_g: wait for them
+        (the buffer is about to be zeroed or reused) and forget the step's bookkeeping."""
+        for h, _ in self._handles:
+            try:
+                h.wait()
+            except Exception:      # noqa: BLE001  (a failed collective must not mask the original error)
+                pass
+        self.reset()
+
+    def _verify(self):
+        """FAVIT_DP_VERIFY: the asynchronously reduced slices against a synchronous reduction of the snapshots."""
+        if buf_is_cuda(self.flat.flat_g):
+            torch.cuda.synchronize()
+        worst = 0.0
+        for b, snap in self._snap:
+            s, e, _ = self.buckets[b]
+            ref = snap.clone()
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)
+            got = self.flat.flat_g[s:e]
+            err = (got - ref).abs().max().item()
+            scale = ref.abs().max().item()
+            worst = max(worst, err / max(scale, 1e-30))
+            if err > 1e-5 * max(scale, 1e-30):
+                raise RuntimeError(f"FAVIT_DP_VERIFY: bucket {b} [{s}:{e}) differs from the synchronous reduction of its "
+                                   f"launch-time snapshot by {err:.3e} (max |ref| {scale:.3e}): a writer of this slice was "
+                                   "not ordered before the collective")
+        self.verified = getattr(self, "verified", 0) + len(self._snap)
+        if _DEBUG:
+            _dbg(f"verify sync#{id(self) % 9973}: {len(self._snap)} buckets, worst relative difference {worst:.2e}")
 
     def finish(self, average: bool = True):
         """Wait for every bucket (launching the ones whose hooks did not fire, e.g. frozen or
@@ -204,6 +254,8 @@ class GradSync:
                 h.wait()
             if _DEBUG:
                 _dbg(f"done sync#{id(self) % 9973}")
+            if _VERIFY:
+                self._verify()
             if average:
                 self.flat.flat_g.mul_(1.0 / self.world)
         self.reset()

@@ -244,12 +244,65 @@ def wcast(w: torch.Tensor) -> torch.Tensor:
     return c
 
 
+def set_dropout_epoch(word: Optional[torch.Tensor]) -> None:
+    """Register (or, with None, clear) the device word every dropout-drawing kernel mixes into its seed at execution
+    time (favit_set_dropout_epoch): a one-element int64 tensor on the current device that the caller increments once per
+    step.  With it, dropout seeds frozen into a captured HIP graph still give fresh masks at every replay."""
+    if word is not None:
+        K.require_gpu(word)
+        if word.dtype != torch.int64 or word.numel() != 1:
+            raise TypeError("the dropout epoch is a one-element int64 device tensor")
+    _STATE["drop_epoch"] = word
+    from . import _abi
+    _abi.check(_abi.lib().favit_set_dropout_epoch(None if word is None else word.data_ptr()), "favit_set_dropout_epoch")
+
+
+def get_dropout_epoch() -> Optional[torch.Tensor]:
+    return _STATE.get("drop_epoch")
+
+
 def _seed() -> int:
     # drawn from torch's CPU generator: reproducible under torch.manual_seed, no device sync
-    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing() and _STATE.get("drop_epoch") is None:
         raise RuntimeError("dropout inside a captured HIP graph: the seed is a kernel argument and would be frozen "
-                           "into the graph (train.GraphedStep needs dropout = 0)")
+                           "into the graph; register a dropout epoch word first (functional.set_dropout_epoch; "
+                           "train.GraphedStep does it for models with dropout)")
     return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+# Backward in segments (train.GraphedStep): models/vit.py::run_encoder splits the block stack into this many autograd
+# nodes and reports the tensors between them.
+_SEG = {"n": 1, "boundaries": []}
+
+
+class encoder_segments:
+    """with encoder_segments(n): forward passes split every encoder into n autograd nodes that are CUT APART: node k + 1
+    reads a detached leaf copy of node k's output.  .boundaries collects the (output of node k, leaf input of node
+    k + 1) pairs in forward order; backward then runs back to front, one autograd call per piece:
+    backward(loss); backward(out_k, grad_tensors=in_{k+1}.grad) ... (train.GraphedStep)."""
+
+    def __init__(self, n: int):
+        self.n = max(1, int(n))
+
+    def __enter__(self):
+        self.prev = (_SEG["n"], _SEG["boundaries"])
+        _SEG["n"], _SEG["boundaries"] = self.n, []
+        self.boundaries = _SEG["boundaries"]
+        return self
+
+    def __exit__(self, *exc):
+        _SEG["n"], _SEG["boundaries"] = self.prev
+        return False
+
+
+def get_encoder_segments() -> int:
+    return _SEG["n"]
+
+
+def note_segment_boundary(x: torch.Tensor) -> torch.Tensor:
+    leaf = x.detach().requires_grad_(True)
+    _SEG["boundaries"].append((x, leaf))
+    return leaf
 
 
 def _as_cdt(x: torch.Tensor) -> torch.Tensor:

@@ -102,12 +102,23 @@ class TransformerBlock(nn.Module):
 
 
 def run_encoder(blocks, x, mask, training):
-    """All blocks of a model as ONE autograd node (no per-block fp32<->bf16 gradient casts)."""
-    specs = [b._spec() for b in blocks]
-    prm = []
-    for b, s in zip(blocks, specs):
-        prm += params(b, s.names)
-    return F.run(F.EncoderOp(specs, F._mask_u8(mask), training), [x], prm)
+    """All blocks of a model as ONE autograd node (no per-block fp32<->bf16 gradient casts) -- or, while
+    functional.encoder_segments(n) is active (train.GraphedStep with backward segments), as n consecutive nodes cut
+    apart at detached boundary tensors, so that backward can be run, and captured, segment by segment."""
+    blocks = list(blocks)
+    nseg = max(1, min(F.get_encoder_segments(), len(blocks)))
+    m = F._mask_u8(mask)
+    per = (len(blocks) + nseg - 1) // nseg
+    for i in range(0, len(blocks), per):
+        grp = blocks[i:i + per]
+        specs = [b._spec() for b in grp]
+        prm = []
+        for b, s in zip(grp, specs):
+            prm += params(b, s.names)
+        if i:
+            x = F.note_segment_boundary(x)        # the next node starts a fresh autograd graph at a leaf copy of x
+        x = F.run(F.EncoderOp(specs, m, training), [x], prm)
+    return x
 
 
 def embed_dropout(x, p, training):

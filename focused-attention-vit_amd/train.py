@@ -101,6 +101,10 @@ class FusedAdamW:
 
     def zero_grad(self):
         for g in self.groups:
+            if g["sync"] is not None and (g["sync"]._handles or any(g["sync"]._launched)):
+                # the previous backward did not reach step() (it raised, or the caller skipped the step): its
+                # all-reduces may still be reading the gradient buffer this call is about to zero
+                g["sync"].abort()
             g["flat"].zero_grad()
             # The bf16 mirror is rewritten by the AdamW kernel and validated per parameter at every use
             # (functional._LPMirror), so eager steps need no refresh here.  A captured step cannot run that host-side
@@ -132,44 +136,111 @@ def train_step(model, images, labels, opt: FusedAdamW):
 
 
 class GraphedStep:
-    """zero_grad -> forward -> cross-entropy -> backward of one training step captured ONCE as a HIP graph
-    and replayed per step; the gradient all-reduce and the fused AdamW run eagerly after each replay.
+    """One training step -- zero_grad -> forward -> cross-entropy -> backward -- captured ONCE in HIP graphs and
+    replayed per step; the gradient all-reduce and the fused AdamW run eagerly.
 
-    For the small-token configurations (SPPP+MHLA: 17 tokens per image) a step is ~600 kernel launches
-    of a few microseconds each and the Python launch path, not the GPU, sets the step time; a replayed
-    graph removes that.  Requirements: FusedAdamW (its bf16 weight mirror is refreshed by kernels, not by
-    host-side caching), fixed shapes, no dropout in training mode (dropout seeds are kernel arguments
-    and would be frozen into the graph), and for SPPP models ``model.assume_num_tokens`` set (the
-    per-forward token-count check is a host sync)."""
+    For the small-token configurations (SPPP+MHLA: 17 tokens per image) a step is ~600 kernel launches of a few
+    microseconds each and the Python launch path, not the GPU, sets the step time; replayed graphs remove that.
+
+    * Dropout (the reference trains with 0.1, main.py:106): seeds are kernel ARGUMENTS and are frozen into the graph,
+      so a device "epoch" word is registered (functional.set_dropout_epoch) that every dropout-drawing kernel mixes
+      into its seed when it EXECUTES; the first captured node increments it, i.e. every replay draws fresh masks and the
+      forward and backward kernels of one replay agree.  An eager step with the same by-value seeds and the same epoch
+      value draws exactly the masks of the replay (tests/test_gpu_modules.py).
+    * Data parallelism: with ``segments`` > 1 the backward is captured as that many graphs (the block stack is split
+      into consecutive autograd nodes, models/vit.py::run_encoder); after launching segment s the host reports the
+      parameters whose gradients segment s completed to dp.GradSync, which puts every finished bucket on the wire
+      while segment s + 1 replays.  ``segments = 1`` (default without a process group) defers every bucket to step().
+
+    Requirements: FusedAdamW (its bf16 weight mirror is refreshed by kernels, not by host-side caching), fixed shapes,
+    and for SPPP models ``model.assume_num_tokens`` set (the per-forward token-count check is a host sync)."""
 
     def __init__(self, model: torch.nn.Module, opt: FusedAdamW, images: torch.Tensor, labels: torch.Tensor,
-                 warmup: int = 3):
+                 warmup: int = 3, segments: Optional[int] = None):
         if K.GEMM_TRACE is not None:
             raise RuntimeError("GraphedStep: disable kernels.GEMM_TRACE (event records cannot be captured)")
         self.model, self.opt = model, opt
         self.x, self.y = images.clone(), labels.clone()
-        syncs = [g["sync"] for g in opt.groups if g["sync"] is not None]
-        for s in syncs:
-            s.defer = True
+        syncs = [g["sync"] for g in opt.groups if g["sync"] is not None and g["sync"]._active]
         self._syncs = syncs
+        if segments is None:
+            segments = 3 if syncs else 1
+        self.segments = max(1, int(segments))
+        for s in syncs:
+            s.defer = True                     # nothing goes out while capturing / replaying: launches are explicit
+        uses_dropout = model.training and any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in model.modules())
+        self.epoch = None
+        if uses_dropout:
+            self.epoch = F.get_dropout_epoch()
+            if self.epoch is None:
+                self.epoch = torch.zeros(1, dtype=torch.int64, device=images.device)
+                F.set_dropout_epoch(self.epoch)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up off the capture stream (lazy kernel attributes, allocator)
             for _ in range(max(1, warmup)):
-                opt.zero_grad()
-                cross_entropy(model(self.x), self.y).backward()
+                self._forward_backward(None)
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            opt.zero_grad()
-            self.loss = cross_entropy(model(self.x), self.y)
-            self.loss.backward()
+        # capture: graph 0 = epoch bump + zero_grad + forward + loss; graphs 1..S = the backward pieces, output side
+        # first.  One memory pool: activations saved by graph 0 are read by the backward graphs.
+        prev_hook = F._STATE["grad_ready"]
+        self._ready: List[List[torch.nn.Parameter]] = []
+        self.graphs: List[torch.cuda.CUDAGraph] = []
+        try:
+            F.set_grad_ready_hook(lambda p: self._ready[-1].append(p))
+            self._forward_backward(self.graphs)
+        finally:
+            F.set_grad_ready_hook(prev_hook)
+        # which parameters are complete after which backward graph: the directly written ones reported themselves;
+        # the others (gradients handed to autograd: cls_token, pos_embed, ...) are counted with the last piece
+        seen = {id(p) for lst in self._ready for p in lst}
+        self._ready[-1].extend(p for g_ in opt.groups for p in g_["flat"].params if id(p) not in seen)
+
+    def _forward_backward(self, graphs):
+        """zero_grad + forward + loss, then backward piece by piece; with a list, every piece is captured in a graph of
+        its own (appended to it), without one it simply runs (warm-up)."""
+        import contextlib
+
+        def scope():
+            if graphs is None:
+                return contextlib.nullcontext()
+            g = torch.cuda.CUDAGraph()
+            pool = graphs[0].pool() if graphs else None
+            graphs.append(g)
+            return torch.cuda.graph(g, pool=pool) if pool is not None else torch.cuda.graph(g)
+
+        with scope():
+            if self.epoch is not None:
+                self.epoch.add_(1)
+            self.opt.zero_grad()
+            with F.encoder_segments(self.segments) as seg:
+                loss = cross_entropy(self.model(self.x), self.y)
+            bounds = list(seg.boundaries)
+        if graphs is not None:
+            self.loss = loss
+        heads, grads = [loss], [None]
+        for k in range(len(bounds), -1, -1):               # the piece that starts at leaf k-1 (k = 0: the input side)
+            if graphs is not None:
+                self._ready.append([])
+            with scope():
+                torch.autograd.backward(heads, grads)
+            if k > 0:
+                out, leaf = bounds[k - 1]
+                heads, grads = [out], [leaf.grad]
 
     def __call__(self, images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
         if images is not self.x:
             self.x.copy_(images, non_blocking=True)
         if labels is not self.y:
             self.y.copy_(labels, non_blocking=True)
-        self.graph.replay()
-        self.opt.step()            # eager: launches every deferred all-reduce bucket, then AdamW
+        self.graphs[0].replay()
+        for g, ready in zip(self.graphs[1:], self._ready):
+            g.replay()
+            if self._syncs and self.segments > 1:
+                for s in self._syncs:
+                    s.defer = False
+                    for p in ready:
+                        s.grad_ready(p)            # buckets completed by this segment go out under the next one
+                    s.defer = True
+        self.opt.step()            # eager: launches whatever is still deferred, waits, then AdamW
         return self.loss

@@ -55,6 +55,13 @@ enum { FAVIT_POOL_MEAN = 0, FAVIT_POOL_MAX = 1, FAVIT_POOL_ATTENTION = 2 };
 int favit_abi_version(void);
 const char* favit_strerror(int code);
 
+/* Dropout epoch: `device_word` (8-byte aligned device pointer, or NULL to switch the feature off) is read by every
+ * kernel that draws a dropout mask -- effective seed = seed + *device_word * 0x9E3779B97F4A7C15 -- at EXECUTION time.
+ * A training step captured once in a HIP graph has its dropout seeds frozen into the kernel arguments; with the
+ * graph's first node incrementing the word, every replay still draws fresh masks, and the forward and backward
+ * kernels of one replay (which recompute the same masks) agree.  Process-wide; the caller owns the word. */
+int favit_set_dropout_epoch(const uint64_t* device_word);
+
 /* ------------------------------------------------------------------------------------
  * GEMM with fused epilogue: every nn.Linear on the path and the dense QK^T / attn.V
  * contractions.   C[m,n] = epilogue( alpha * sum_k A[m,k] * B[n,k] )

@@ -111,6 +111,7 @@ def _accum_worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["FAVIT_DP_VERIFY"] = "1"                  # (read at import) ordering check of every bucket, dp.py
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = importlib.import_module("focused-attention-vit_amd")
     torch.manual_seed(5)
@@ -140,6 +141,26 @@ def _accum_worker(rank, world, port, out):
         assert all(sync._launched), "every bucket's all-reduce must have been launched by the ready events"
         sync.finish(average=False)
     good = [p.grad.clone() for p in params]
+    verified = getattr(sync, "verified", 0)
+    # a writer that is NOT ordered before its bucket's collective (here: a late in-place edit without grad_ready) is
+    # what FAVIT_DP_VERIFY exists to catch: the asynchronous result no longer equals the reduced launch-time snapshot
+    verify_err = ""
+    flat.zero_grad()
+    backward(micro[0])
+    for h, _ in sync._handles:
+        h.wait()
+    params[0].grad.add_(1.0)                             # "a kernel still writing the slice" after the launch
+    try:
+        sync.finish(average=False)
+    except RuntimeError as e:
+        verify_err = str(e)
+        sync.reset()
+    # a backward that raised leaves launched buckets behind: abort() (FusedAdamW.zero_grad calls it) clears them
+    flat.zero_grad()
+    backward(micro[0])
+    assert any(sync._launched)
+    sync.abort()
+    assert not any(sync._launched) and not sync._handles
     # accumulating WITHOUT no_sync after the buckets were launched must fail loudly, not corrupt silently
     err = ""
     flat.zero_grad()
@@ -148,9 +169,9 @@ def _accum_worker(rank, world, port, out):
         backward(micro[1])
     except RuntimeError as e:
         err = str(e)
-    sync.finish(average=False)
+    sync.abort()                                         # the failed step's collectives are drained, nothing is kept
     if rank == 0:
-        torch.save({"grads": good, "err": err}, out)
+        torch.save({"grads": good, "err": err, "verify_err": verify_err, "verified": verified}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -160,7 +181,9 @@ def test_dp_direct_grads_with_accumulation(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_accum_worker, args=(2, port, out), nprocs=2, join=True)
     got = torch.load(out, weights_only=True)
-    assert "no_sync" in got["err"]
+    assert "no_sync" in got["err"] and "weight sharing" in got["err"]
+    assert got["verified"] >= 6, "FAVIT_DP_VERIFY checked every bucket of both steps"
+    assert "FAVIT_DP_VERIFY" in got["verify_err"], "an unordered writer must be reported"
     # finish(average=False) leaves SUMS over ranks (1/world is folded into the optimizer's gradient scale)
     ref = [sum(_acc_micro(r)[0][i] + _acc_micro(r)[1][i] for r in range(2)) for i in range(len(_ACC_SHAPES))]
     for g, r in zip(got["grads"], ref):

@@ -33,6 +33,7 @@ def _worker(rank, world, port, out, mode):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["FAVIT_DP_VERIFY"] = "1"                     # ordering check of every bucket against its launch-time snapshot
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = importlib.import_module("focused-attention-vit_amd")
@@ -87,6 +88,7 @@ def _nccl_worker(rank, port, out):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["FAVIT_DP_FORCE"] = "1"                      # one rank, but issue every collective
+    os.environ["FAVIT_DP_VERIFY"] = "1"                     # and check each against its launch-time snapshot (dp.py)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     pkg = importlib.import_module("focused-attention-vit_amd")
@@ -105,7 +107,9 @@ def _nccl_worker(rank, port, out):
     grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
     losses = [float(pkg.train.train_step(m, xs, ys, opt)) for _ in range(3)]
     torch.cuda.synchronize()
-    torch.save({"grads": grads, "launched": launched, "n_handles": n_handles, "n_buckets": n_buckets, "losses": losses}, out)
+    verified = sum(getattr(g["sync"], "verified", 0) for g in opt.groups)
+    torch.save({"grads": grads, "launched": launched, "n_handles": n_handles, "n_buckets": n_buckets, "losses": losses,
+                "verified": verified}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -120,6 +124,7 @@ def test_rccl_call_path_single_rank(favit, tmp_path):
     mp.spawn(_nccl_worker, args=(34500 + (os.getpid() % 2000), out), nprocs=1, join=True)
     r = torch.load(out, weights_only=True)
     assert all(r["launched"]) and r["n_handles"] == r["n_buckets"] >= 3
+    assert r["verified"] >= 4 * r["n_buckets"], "FAVIT_DP_VERIFY: every bucket of every step equals its ordered snapshot"
     assert r["losses"][-1] < r["losses"][0]
     favit.set_compute_dtype("bf16")
     try:
@@ -132,3 +137,86 @@ def test_rccl_call_path_single_rank(favit, tmp_path):
             assert err < 2e-2, (k, float(err))
     finally:
         favit.set_compute_dtype("fp32")
+
+
+def _graph_worker(rank, world, port, out):
+    """Two ranks, each replaying a 3-segment GraphedStep: buckets completed by a backward segment must be launched
+    BEFORE the last segment's graph is replayed (they overlap it on RCCL), and the ranks must stay in lock-step."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["FAVIT_DP_VERIFY"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("focused-attention-vit_amd")
+    pkg.set_compute_dtype("bf16")
+    torch.manual_seed(3)
+    m = pkg.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=6,
+                                                  num_heads=4, window_size=7, use_mhla=True).cuda().train()
+    opt = pkg.train.FusedAdamW(pkg.train.param_groups(m, lr=1e-2), lr=1e-2, weight_decay=0.0, bucket_mb=0.05)
+    x, y = _batch()
+    lo = rank * 4
+    xs, ys = x[lo:lo + 4].cuda(), y[lo:lo + 4].cuda()
+    step = pkg.train.GraphedStep(m, opt, xs, ys, segments=3)
+    assert len(step.graphs) == 4
+    # log (bucket, number of backward graphs replayed so far) at every launch
+    replayed = {"n": 0}
+    log = []
+
+    class Proxy:
+        def __init__(self, g, backward):
+            self.g, self.backward = g, backward
+
+        def replay(self):
+            self.g.replay()
+            if self.backward:
+                replayed["n"] += 1
+    step.graphs = [Proxy(g, i > 0) for i, g in enumerate(step.graphs)]
+    for g_ in opt.groups:
+        sync = g_["sync"]
+        orig = sync._launch
+
+        def wrapped(b, _orig=orig, _sync=sync):
+            if not _sync._launched[b]:
+                log.append((b, replayed["n"]))
+            _orig(b)
+        sync._launch = wrapped
+    losses = []
+    for _ in range(2):
+        replayed["n"] = 0
+        losses.append(float(step(xs, ys)))
+    torch.cuda.synchronize()
+    w = torch.cat([p.detach().flatten().cpu() for p in m.parameters()])
+    verified = sum(getattr(g_["sync"], "verified", 0) for g_ in opt.groups)
+    torch.save({"w": w, "log": log, "losses": losses, "verified": verified,
+                "n_buckets": sum(len(g_["sync"].buckets) for g_ in opt.groups)}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_graphed_step_launches_buckets_between_backward_segments(favit, tmp_path):
+    out = str(tmp_path / "gdp")
+    mp.spawn(_graph_worker, args=(2, 35500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0", weights_only=True), torch.load(out + ".1", weights_only=True)
+    assert torch.equal(r0["w"], r1["w"]), "the two ranks diverged"
+    for r in (r0, r1):
+        early = [b for b, n in r["log"] if n < 3]
+        assert len(r["log"]) == 2 * r["n_buckets"], r["log"]
+        assert len(early) >= 2, f"no bucket went out before the last backward segment: {r['log']}"
+        assert r["verified"] == 2 * r["n_buckets"]
+        assert r["losses"][1] < r["losses"][0]
+    # same trajectory as one process training on the whole batch (mean over 8 = mean of the two rank means)
+    favit.set_compute_dtype("bf16")
+    try:
+        torch.manual_seed(3)
+        m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=6,
+                                                        num_heads=4, window_size=7, use_mhla=True).cuda().train()
+        opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=1e-2), lr=1e-2, weight_decay=0.0, distributed=False)
+        x, y = _batch()
+        for _ in range(2):
+            favit.train.train_step(m, x.cuda(), y.cuda(), opt)
+        w = torch.cat([p.detach().flatten().cpu() for p in m.parameters()])
+        assert (r0["w"] - w).norm() / w.norm() < 2e-3
+    finally:
+        favit.set_compute_dtype("fp32")
+        favit.functional.clear_lp_mirrors()

@@ -130,6 +130,54 @@ def test_dropout_draws_are_uniform_and_independent_across_seeds(K):
         assert abs(float(mask(99, p).mean()) - (1 - p)) < tol
 
 
+def test_dropout_epoch_word_changes_the_masks(K, favit):
+    """favit_set_dropout_epoch: the device word is mixed into every dropout seed at execution time (GEMM epilogue,
+    stand-alone dropout, MHLA and dense attention).  Epoch 0 == no word; different epochs give different masks with the
+    same keep rate; the GEMM epilogue and the dropout kernel stay consistent with each other under one epoch."""
+    F = favit.functional
+    g = torch.Generator(device=DEV).manual_seed(8)
+    x = torch.ones(64 * 1024, device=DEV)
+    base = K.dropout(x, 0.3, 1234)
+    ep = torch.zeros(1, dtype=torch.int64, device=DEV)
+    try:
+        F.set_dropout_epoch(ep)
+        assert torch.equal(K.dropout(x, 0.3, 1234), base), "epoch 0 must reproduce the by-value seed"
+        ep.fill_(1)
+        m1 = K.dropout(x, 0.3, 1234)
+        ep.fill_(2)
+        m2 = K.dropout(x, 0.3, 1234)
+        assert not torch.equal(m1, base) and not torch.equal(m1, m2)
+        for m in (m1, m2):
+            assert abs((m == 0).float().mean().item() - 0.3) < 0.01
+        agree = ((m1 == 0) == (m2 == 0)).float().mean().item()
+        assert abs(agree - (0.3 * 0.3 + 0.7 * 0.7)) < 0.01, "masks of different epochs are independent"
+        # GEMM epilogue under the same epoch == dropout kernel under the same epoch (index = m * N + n)
+        M, N, Kd = 300, 256, 64
+        a = _rand((M, Kd), torch.float32, g)
+        b = _rand((N, Kd), torch.float32, g)
+        out = torch.empty((M, N), device=DEV)
+        K.gemm(a, b, out, M, N, Kd, Kd, Kd, N, dropout_p=0.25, dropout_seed=77)
+        plain = torch.empty((M, N), device=DEV)
+        K.gemm(a, b, plain, M, N, Kd, Kd, Kd, N)
+        assert rel_l2(out, K.dropout(plain, 0.25, 77)) < 1e-6
+        # attention: forward / backward mask consistency holds under a non-zero epoch (<dout, out(V)> == <dV, V>)
+        B, H, L, hd, W = 2, 2, 40, 64, 7
+        D = H * hd
+        qkv = _rand((B * L, 3 * D), torch.bfloat16, g)
+        dout = _rand((B * L, D), torch.bfloat16, g)
+        o = K.mhla_attn_fwd(qkv, B, L, H, hd, W, None, 0.25, 9)
+        dqkv = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, None, 0.25, 9)
+        lhs = (dout.float() * o.float()).sum().item()
+        rhs = (dqkv[:, 2 * D:].float() * qkv[:, 2 * D:].float()).sum().item()
+        assert abs(lhs - rhs) < 3e-2 * (dout.float() * o.float()).pow(2).sum().sqrt().item()
+        ep.fill_(0)
+        o0 = K.mhla_attn_fwd(qkv, B, L, H, hd, W, None, 0.25, 9)
+        assert not torch.equal(o0, o)
+    finally:
+        F.set_dropout_epoch(None)
+    assert torch.equal(K.dropout(x, 0.3, 1234), base)
+
+
 def test_gemm_dropout_epilogue_matches_dropout_kernel(K):
     g = torch.Generator(device=DEV).manual_seed(13)
     M, N, Kd = 256, 128, 64

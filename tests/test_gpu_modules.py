@@ -429,13 +429,96 @@ def test_graphed_step_matches_eager_steps(favit):
     w1 = torch.cat([p.detach().flatten() for p in m1.parameters()])
     w2 = torch.cat([p.detach().flatten() for p in m2.parameters()])
     assert rel_l2(w2.cpu(), w1.cpu()) < 1e-3
-    # dropout cannot be captured (its seed is a kernel argument)
-    torch.manual_seed(11)
-    m3 = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2,
-                                                    num_heads=4, use_mhla=True, dropout=0.1).to(DEV).train()
-    o3 = favit.train.FusedAdamW(favit.train.param_groups(m3, lr=1e-3), lr=1e-3, distributed=False)
-    with pytest.raises(RuntimeError):
-        favit.train.GraphedStep(m3, o3, xs[0], ys[0], warmup=1)
+
+
+def test_graphed_step_with_dropout_matches_eager_steps(favit, monkeypatch):
+    """The reference's training setting (dropout = attn_dropout = embed_dropout = 0.1, main.py:106) through
+    train.GraphedStep: dropout seeds are frozen into the captured kernels, a device epoch word (bumped by the graph's
+    first node) is mixed in at execution time.  For the SAME by-value seeds and the SAME epoch values the eager path
+    draws the same masks: the two trajectories agree, and consecutive replays differ from each other (fresh masks)."""
+    favit.set_compute_dtype("bf16")
+    F = favit.functional
+    counter = {"n": 0}
+
+    def fake_seed():
+        counter["n"] += 1
+        return 0x5DEECE66D * counter["n"] + 11
+
+    monkeypatch.setattr(F, "_seed", fake_seed)
+
+    def build():
+        torch.manual_seed(11)
+        m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2,
+                                                        num_heads=4, use_mhla=True, dropout=0.1, attn_dropout=0.1,
+                                                        embed_dropout=0.1).to(DEV).train()
+        opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=1e-3), lr=1e-3, weight_decay=0.05, distributed=False)
+        return m, opt
+    g = torch.Generator(device=DEV).manual_seed(2)
+    xs = [torch.randn(8, 3, 32, 32, device=DEV, generator=g) for _ in range(3)]
+    ys = [torch.randint(0, 10, (8,), device=DEV, generator=g) for _ in range(3)]
+    try:
+        # graphed: one warm-up pass (seeds 1..n, epoch -> 1), the capture draws seeds n+1..2n, replays run at epoch 2, 3, 4
+        m2, o2 = build()
+        counter["n"] = 0
+        step = favit.train.GraphedStep(m2, o2, xs[0], ys[0], warmup=1)
+        assert step.epoch is not None and F.get_dropout_epoch() is step.epoch
+        n = counter["n"] // 2
+        assert n >= 9 and counter["n"] == 2 * n           # embed + 2 x (attention, proj, 2 x MLP) sites
+        graphed = [step(x, y).item() for x, y in zip(xs, ys)]
+        assert int(step.epoch.item()) == 4
+        # eager with the capture's seeds and the replays' epoch values
+        m1, o1 = build()
+        eager = []
+        for k, (x, y) in enumerate(zip(xs, ys)):
+            counter["n"] = n
+            step.epoch.fill_(k + 2)
+            eager.append(favit.train.train_step(m1, x, y, o1).item())
+        for a, b in zip(eager, graphed):
+            assert abs(a - b) < 2e-3 * max(1.0, abs(a)), (eager, graphed)
+        w1 = torch.cat([p.detach().flatten() for p in m1.parameters()])
+        w2 = torch.cat([p.detach().flatten() for p in m2.parameters()])
+        assert rel_l2(w2.cpu(), w1.cpu()) < 1e-3
+    finally:
+        F.set_dropout_epoch(None)
+        favit.set_compute_dtype("fp32")
+        favit.functional.clear_lp_mirrors()
+
+
+def test_graphed_step_backward_segments_match_the_single_graph(favit):
+    """segments = 3: the backward captured as three graphs cut at detached boundaries (the form that lets GradSync put
+    finished buckets on the wire between replays) walks the same trajectory as the single-graph and the eager step."""
+    favit.set_compute_dtype("bf16")
+
+    def build():
+        torch.manual_seed(13)
+        m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=6,
+                                                        num_heads=4, use_mhla=True).to(DEV).train()
+        opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=1e-3), lr=1e-3, weight_decay=0.05, distributed=False)
+        return m, opt
+    g = torch.Generator(device=DEV).manual_seed(4)
+    xs = [torch.randn(8, 3, 32, 32, device=DEV, generator=g) for _ in range(3)]
+    ys = [torch.randint(0, 10, (8,), device=DEV, generator=g) for _ in range(3)]
+    try:
+        m1, o1 = build()
+        eager = [favit.train.train_step(m1, x, y, o1).item() for x, y in zip(xs, ys)]
+        m3, o3 = build()
+        step = favit.train.GraphedStep(m3, o3, xs[0], ys[0], segments=3)
+        assert len(step.graphs) == 4 and len(step._ready) == 3
+        names = {id(p): k for k, p in m3.named_parameters()}
+        first = {names[id(p)] for p in step._ready[0]}
+        last = {names[id(p)] for p in step._ready[-1]}
+        assert "head.weight" in first and "blocks.5.mlp.fc2.weight" in first and "blocks.0.attn.qkv.weight" not in first
+        assert "blocks.0.attn.qkv.weight" in last and "cls_token" in last and "patch_embed.projection.1.weight" in last
+        assert sum(len(r) for r in step._ready) == len(names)
+        seg = [step(x, y).item() for x, y in zip(xs, ys)]
+        for a, b in zip(eager, seg):
+            assert abs(a - b) < 2e-3 * max(1.0, abs(a)), (eager, seg)
+        w1 = torch.cat([p.detach().flatten() for p in m1.parameters()])
+        w3 = torch.cat([p.detach().flatten() for p in m3.parameters()])
+        assert rel_l2(w3.cpu(), w1.cpu()) < 1e-3
+    finally:
+        favit.set_compute_dtype("fp32")
+        favit.functional.clear_lp_mirrors()
 
 
 @pytest.mark.parametrize("mode", ["bf16", "fp8"])
