@@ -109,18 +109,33 @@ __global__ __launch_bounds__(256) void slic_features_kernel(const float* __restr
   short* o = feat + p * 4;
   for (int c = 0; c < 3; ++c) {
     float q = rintf(lab[c] * 16.0f);
-    q = fminf(fmaxf(q, -32000.f), 32000.f);
+    q = fminf(fmaxf(q, -8191.f), 8191.f);       // 13 bits + sign (CIELAB x 16 of an sRGB colour stays inside +-2048):
+                                                // differences fit 24-bit multiplies, three squares fit 32 bits
     o[c] = (short)q;
   }
   o[3] = 0;
 }
 
-// sum of v over the lanes in `mask` (all lanes execute; lanes outside contribute 0)
+// sum of v over the lanes in `mask` (all lanes execute; lanes outside contribute 0), entirely in the VALU: four DPP
+// steps inside each row of 16 lanes (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the
+// gfx950 row swaps v_permlane16_swap / v_permlane32_swap across the four rows.  (__shfl_xor is ds_bpermute_b32: six
+// round trips through the LDS crossbar per sum, five sums per cluster group and wave.)
+__device__ __forceinline__ int dpp_sum16_i(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+  return v;
+}
 __device__ __forceinline__ int masked_wave_sum(int v, bool in) {
-  int s = in ? v : 0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  return s;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  int s = dpp_sum16_i(in ? v : 0);
+  unsigned u = (unsigned)s;
+  u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u += ((threadIdx.x >> 4) & 1) ? r.x : r.y;
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u += ((threadIdx.x >> 5) & 1) ? r.x : r.y;
+  return (int)u;
 }
 
 // ---- stage 2: k-means, one launch pair per iteration, every pixel of every image in parallel ----
@@ -152,6 +167,10 @@ __global__ __launch_bounds__(64) void slic_seed_kernel(const short* __restrict__
   for (int c = 0; c < 6; ++c) sm[c] = 0;
 }
 
+// FAST (H, W <= 2047 and coef < 2^32, i.e. every real call): the five differences fit 24-bit multiplies (full rate;
+// v_mul_lo_u32 / v_mad_i64_i32 run at a quarter of it), the spatial and colour sums fit 32 bits and the distance is
+// ONE v_mad_u64_u32 -- the same integers as the 64-bit form, which stays for out-of-range arguments.
+template <bool FAST>
 __global__ __launch_bounds__(SLIC_THREADS) void slic_assign_kernel(const short* __restrict__ feat, uint8_t* __restrict__ labels,
                                                                    void* ws, int K, int H, int W, int step, long long coef) {
   __shared__ int cen[SLIC_MAXK][5];      // y16, x16, l, a, b
@@ -171,16 +190,24 @@ __global__ __launch_bounds__(SLIC_THREADS) void slic_assign_kernel(const short* 
     y = p / W; x = p - y * W;
     const short* q = f + (long)p * 4;
     q0 = q[0]; q1 = q[1]; q2 = q[2];
-    long long best = 0x7fffffffffffffffLL;
+    unsigned long long best = ~0ull;
+    const unsigned coef32 = (unsigned)coef;
     for (int k = 0; k < K; ++k) {
       const int cy = cen[k][0] >> 4, cx = cen[k][1] >> 4;                 // int(centre), centres are >= 0
       if (y < cy - 2 * step || y > cy + 2 * step || x < cx - 2 * step || x > cx + 2 * step) continue;
-      // 32-bit differences, 32x32 -> 64-bit products (one v_mad_i64_i32 each): the same integers as 64-bit arithmetic
       const int dy = 16 * y - cen[k][0], dx = 16 * x - cen[k][1];
       const int dl = q0 - cen[k][2], da = q1 - cen[k][3], db = q2 - cen[k][4];
-      const long long sp = (long long)dy * dy + (long long)dx * dx;
-      const long long cq = (long long)dl * dl + (long long)da * da + (long long)db * db;
-      const long long d = sp + coef * cq;
+      unsigned long long d;
+      if (FAST) {
+        const unsigned sp = (unsigned)__mul24(dy, dy) + (unsigned)__mul24(dx, dx);
+        const unsigned cq = (unsigned)__mul24(dl, dl) + (unsigned)__mul24(da, da) + (unsigned)__mul24(db, db);
+        d = (unsigned long long)coef32 * cq + sp;
+      } else {
+        // 32-bit differences, 32x32 -> 64-bit products: the same integers as 64-bit arithmetic throughout
+        const long long sp = (long long)dy * dy + (long long)dx * dx;
+        const long long cq = (long long)dl * dl + (long long)da * da + (long long)db * db;
+        d = (unsigned long long)(sp + coef * cq);
+      }
       if (d < best) { best = d; best_k = k; }
     }
     if (best_k == 255) best_k = lab[p];                                    // no window covers the pixel: keep
@@ -372,8 +399,12 @@ extern "C" int favit_slic_cluster(const int16_t* feat, uint8_t* labels, const in
   FAVIT_CHECK_LAUNCH();
   const dim3 grid((unsigned)((HW + SLIC_THREADS - 1) / SLIC_THREADS), (unsigned)B);
   for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL(slic_assign_kernel, grid, dim3(SLIC_THREADS), 0, st, reinterpret_cast<const short*>(feat), labels, ws, K,
-                       H, W, step, (long long)coef);
+    if (H <= 2047 && W <= 2047 && coef < (1LL << 32))
+      hipLaunchKernelGGL(slic_assign_kernel<true>, grid, dim3(SLIC_THREADS), 0, st, reinterpret_cast<const short*>(feat), labels,
+                         ws, K, H, W, step, (long long)coef);
+    else
+      hipLaunchKernelGGL(slic_assign_kernel<false>, grid, dim3(SLIC_THREADS), 0, st, reinterpret_cast<const short*>(feat), labels,
+                         ws, K, H, W, step, (long long)coef);
     FAVIT_CHECK_LAUNCH();
     hipLaunchKernelGGL(slic_update_kernel, dim3((unsigned)B), dim3(64), 0, st, ws, K);
     FAVIT_CHECK_LAUNCH();

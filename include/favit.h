@@ -265,11 +265,12 @@ int favit_image_transform(const uint8_t* src, uint8_t* tmp, float* out, uint8_t*
  * dependency absent from the image: parity with skimage is UNPINNED; the algorithm (csrc/slic.hip header) is the
  * published SLIC as skimage parametrises it, integer-exact after the colour conversion, and is checked against
  * the CPU restatement oracle/slic_oracle.py.
- *   features: img fp32 [B,3,H,W] -> feat int16 [B,H*W,4] = round(16 * CIELAB(gaussian_sigma(rescale(img)))), lane 3 = 0;
+ *   features: img fp32 [B,3,H,W] -> feat int16 [B,H*W,4] = round(16 * CIELAB(gaussian_sigma(rescale(img)))) clamped to +-8191, lane 3 = 0;
  *             minmax: device workspace of 2*B floats -> every image is first rescaled to [0, 1] by its own minimum and
  *             maximum over all channels, as scikit-image >= 0.19 does before smoothing (the reference passes
  *             mean/std-normalised tensors, models/sppp_mhla.py:278); NULL = no rescale (scikit-image < 0.19)
- *   cluster : k-means, K <= 64 centres seeded at init_yx [K,2] (int32 y, x), window +-2*step, distance
+ *   cluster : (feat values must lie in [-8191, 8191], as `features` produces them: the distance arithmetic relies on it)
+ *             k-means, K <= 64 centres seeded at init_yx [K,2] (int32 y, x), window +-2*step, distance
  *             256*spatial^2 + coef*dq^2 (int64), `iters` rounds -> labels uint8 [B,H*W]; ws: 8-byte aligned device
  *             workspace of favit_slic_cluster_workspace(K, B) bytes (per-centre sums and coordinates)
  *   connect : 4-connected components in raster order, components < min_size merged into a labelled neighbour,

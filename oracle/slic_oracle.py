@@ -61,7 +61,7 @@ def features(img, sigma, rescale=True):
     xyz = np.einsum("ij,jyx->iyx", M, lin) / np.array([0.95047, 1.0, 1.08883])[:, None, None]
     f = np.where(xyz > 0.008856, np.cbrt(xyz), 7.787 * xyz + 16.0 / 116.0)
     lab = np.stack([116.0 * f[1] - 16.0, 500.0 * (f[0] - f[1]), 200.0 * (f[1] - f[2])], -1)
-    return np.clip(np.rint(lab * 16.0), -32000, 32000).astype(np.int16).reshape(H * W, 3)
+    return np.clip(np.rint(lab * 16.0), -8191, 8191).astype(np.int16).reshape(H * W, 3)
 
 
 def _tdiv(a, b):

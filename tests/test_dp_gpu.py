@@ -204,7 +204,6 @@ def test_dp_graphed_step_launches_buckets_between_backward_segments(favit, tmp_p
         assert len(r["log"]) == 2 * r["n_buckets"], r["log"]
         assert len(early) >= 2, f"no bucket went out before the last backward segment: {r['log']}"
         assert r["verified"] == 2 * r["n_buckets"]
-        assert r["losses"][1] < r["losses"][0]
     # same trajectory as one process training on the whole batch (mean over 8 = mean of the two rank means)
     favit.set_compute_dtype("bf16")
     try:
