@@ -37,7 +37,54 @@ HBM_PEAK_GBPS = 8000.0
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MFMA_PEAK_TFLOPS = 157.3
 FP8_DENSE_PEAK_TFLOPS = 5000.0
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+PROFILE_DIR = os.path.join(ROOT, "profiles")
+
+
+def traffic_profile(cfg, dtype):
+    """The newest committed PMC traffic profile of this configuration / dtype (profiles/rNN_pmc_hbm_traffic*.json,
+    written by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(PROFILE_DIR, "r*_pmc_hbm_traffic*.json"))):
+        try:
+            with open(f) as fh:
+                prof = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if prof.get("config", "cfg2") == cfg and prof.get("dtype", "bf16") == dtype:
+            best = (f, prof)
+    return best
+
+
+def match_gemm_kernels(prof, key, tag):
+    """Kernels of a traffic profile that belong to the GEMM family `key` (dtype_layout_out, kernels.GEMM_TRACE) as the
+    library dispatched it (`tag`: favit_gemm_last_kernel).  Returns (bytes per launch averaged over launches, names)."""
+    base = {"p4": "gemm_fp8_p4_kernel" if key.startswith("fp8") else "gemm_bf16_p4_kernel", "p7": "gemm_bf16_p7_kernel",
+            "pp": "gemm_bf16_pp_kernel", "s64": "gemm_bf16_s64_kernel", "grouped_tn": "gemm_bf16_p4_grouped_tn_kernel",
+            "t128": "gemm_"}.get(tag, "gemm_")
+    ak, bk = key.split("_")[1][0] == "K", key.split("_")[1][1] == "K"
+    of32 = key.endswith("of32") or key.endswith("grouped")
+    tot_b = tot_n = 0.0
+    names = []
+    for e in prof.get("kernels", []):
+        n = e["kernel"]
+        if base not in n or ("grouped" in n) != (tag == "grouped_tn"):
+            continue
+        demangled = "<" in n
+        if tag in ("p4", "t128") and not key.startswith("fp8"):
+            flags = (f"<{str(ak).lower()}, {str(bk).lower()}," if demangled else f"ILb{int(ak)}ELb{int(bk)}E")
+            if flags not in n:
+                continue
+        if tag in ("s64", "pp"):
+            flag = (f"<{str(bk).lower()}," if demangled else f"ILb{int(bk)}E")
+            if flag not in n:
+                continue
+        is_f32 = ("float" in n.split("(")[0]) if demangled else (n.rstrip("E").endswith("f") or "EfE" in n or "IfE" in n)
+        if is_f32 != of32:
+            continue
+        tot_b += e["hbm_bytes_per_launch"] * e["launches_per_step"]
+        tot_n += e["launches_per_step"]
+        names.append(n[:60])
+    return (tot_b / tot_n if tot_n else None), names
 
 
 def flops_per_image_train(L, D, depth, hd, W, N, P, C, classes, dense=False):
@@ -78,6 +125,12 @@ CONFIGS = {
     "cfg4": dict(name="ViT-MHLA-Base (D768/12L/12H, window 7) 384x384 patch16, 577 tokens", batch=64, img=384,
                  classes=1000, flops=dict(L=577, D=768, depth=12, hd=64, W=7, N=576, P=16, C=3, classes=1000),
                  metric="images/sec (train fwd+bwd) ViT-MHLA-Base 384/p16", cpu_batch=2, cpu_steps=4),
+    # experiments/sppp_mhla_pretrained.py:236-247,337-346: identity latent_proj, everything frozen except head and
+    # latent_proj, per-name learning rates, batches bucketed by superpixel-token count (R = 16 and R = 15 alternate)
+    "cfg5": dict(name="SPPP+MHLA Small fine-tune (identity latent_proj; only head + latent_proj trainable; alternating "
+                      "R = 16 / R = 15 superpixel-token buckets) 224x224 patch16, HIP-graph replayed steps", batch=128,
+                 img=224, classes=1000, flops=dict(L=17, D=384, depth=12, hd=64, W=7, N=196, P=16, C=3, classes=1000),
+                 metric="images/sec (fine-tune fwd+bwd) SPPP+MHLA 224/p16", cpu_batch=16, cpu_steps=12),
 }
 
 
@@ -90,9 +143,17 @@ def build_model(pkg, cfg, dev, dropout=0.0):
         return M.vit_mhla.VisionTransformerMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12,
                                                 num_heads=6, window_size=7, use_mhla=True, dropout=d,
                                                 attn_dropout=d, embed_dropout=d).to(dev)
-    if cfg == "cfg3":
-        return M.sppp_mhla.SPPPViTMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12, num_heads=6,
-                                       num_superpixels=16, pooling_type="mean", window_size=7, use_mhla=True).to(dev)
+    if cfg in ("cfg3", "cfg5"):
+        m = M.sppp_mhla.SPPPViTMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12, num_heads=6,
+                                    num_superpixels=16, pooling_type="mean", window_size=7, use_mhla=True)
+        if cfg == "cfg5":
+            for blk in m.blocks:                       # experiments/sppp_mhla_pretrained.py:236-237
+                torch.nn.init.eye_(blk.attn.latent_proj.weight)
+                torch.nn.init.zeros_(blk.attn.latent_proj.bias)
+            for name, p_ in m.named_parameters():      # :243-247 (freeze_layers=True)
+                if not any(x in name for x in ("head", "latent_proj", "segmentation", "patch_mapper", "pooling")):
+                    p_.requires_grad = False
+        return m.to(dev)
     return M.vit_mhla.VisionTransformerMHLA(img_size=384, patch_size=16, num_classes=1000, embed_dim=768, depth=12,
                                             num_heads=12, window_size=7, use_mhla=True, dropout=d, attn_dropout=d,
                                             embed_dropout=d).to(dev)
@@ -137,7 +198,8 @@ def cpu_baseline(cfg, model, segs_np):
     torch.set_num_threads(cores)
     log(f"cpu_baseline on {cores} host cores")
     batch, steps = c["cpu_batch"], c["cpu_steps"]
-    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    trainable = {k for k, p_ in model.named_parameters() if p_.requires_grad}
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(k in trainable) for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(batch, 3, c["img"], c["img"], generator=g)
     y = torch.randint(0, c["classes"], (batch,), generator=g)
@@ -147,7 +209,7 @@ def cpu_baseline(cfg, model, segs_np):
             return O.vit_forward(x, sd, 4, 3)
         if cfg == "cfg2":
             return O.vit_mhla_forward(x, sd, 16, 6, 7, True)
-        if cfg == "cfg3":
+        if cfg in ("cfg3", "cfg5"):
             return O.sppp_vit_mhla_forward(x, segs_np[:batch], sd, 16, 6, 7, True)
         return O.vit_mhla_forward(x, sd, 16, 12, 7, True)
 
@@ -214,6 +276,9 @@ def main():
                     help="dropout = attn_dropout = embed_dropout of the cfg2 / cfg4 models (the reference's main.py:106 "
                          "trains with 0.1; the headline row is 0.0, SURVEY 8d)")
     ap.add_argument("--bucket-mb", type=float, default=0.0, help="all-reduce bucket size in MiB (default: dp.GradSync's own choice)")
+    ap.add_argument("--slic", action="store_true",
+                    help="cfg3: also time the step WITH the device SLIC inside it (label maps recomputed from the batch every "
+                         "step instead of installed once); reported as `slic_inclusive`, never as `value`")
     ap.add_argument("--host-input", action="store_true",
                     help="also measure the PCIe-inclusive rate: uint8 HWC batches in pinned HOST memory -> async copy + "
                          "device transform (data.DeviceLoader) -> step; reported as `pcie_inclusive`, never as `value`")
@@ -252,15 +317,43 @@ def main():
     images = torch.randn(B, 3, c["img"], c["img"], device=dev, generator=g)
     labels = torch.randint(0, c["classes"], (B,), device=dev, generator=g)
     segs_np = None
-    if args.config == "cfg3":
+    segs = segs15 = None
+    if args.config in ("cfg3", "cfg5"):
         segs_np = synthetic_label_maps(8, 224, 16, seed=100 + rank)
         segs = torch.from_numpy(np.stack([segs_np[i % 8] for i in range(B)])).to(dev)
         model.segmentation.set_label_maps(segs)
+        if args.config == "cfg5":                    # the R = 15 bucket: regions 14 and 15 merged
+            segs15 = torch.where(segs == 15, torch.full_like(segs, 14), segs)
         segs_np = np.stack([segs_np[i % 8] for i in range(max(B, c["cpu_batch"]))])
-    opt = pkg.train.FusedAdamW(pkg.train.param_groups(model, lr=1e-4), lr=1e-4, weight_decay=0.05,
-                               bucket_mb=args.bucket_mb or None)
-    graphed = args.config in ("cfg1", "cfg3") and not args.no_graph
-    if graphed:
+    if args.config == "cfg5":
+        # the reference's frozen-layers branch gives every trainable tensor its own group: head at head_lr, the rest
+        # (latent_proj) at lr (experiments/sppp_mhla_pretrained.py:337-346)
+        groups = pkg.train.param_groups(model, lr=1e-4, head_lr=1e-3, latent_lr_mult=1.0)
+    else:
+        groups = pkg.train.param_groups(model, lr=1e-4)
+    opt = pkg.train.FusedAdamW(groups, lr=1e-4, weight_decay=0.05, bucket_mb=args.bucket_mb or None)
+    graphed = args.config in ("cfg1", "cfg3", "cfg5") and not args.no_graph
+    gstep = None
+    if args.config == "cfg5":
+        buckets = []
+        for maps, R in ((segs, 16), (segs15, 15)):
+            model.segmentation.set_label_maps(maps)
+            model.assume_num_tokens = R
+            if graphed:
+                g_ = pkg.train.GraphedStep(model, opt, images, labels)
+                buckets.append(lambda g_=g_: g_(images, labels))
+            else:
+                def eager(maps=maps, R=R):
+                    model.segmentation.set_label_maps(maps)
+                    model.assume_num_tokens = R
+                    return pkg.train.train_step(model, images, labels, opt)
+                buckets.append(eager)
+        turn = {"i": 0}
+
+        def step():
+            turn["i"] += 1
+            return buckets[turn["i"] % 2]()
+    elif graphed:
         # hundreds of launches of a few microseconds per step: the Python launch path, not the GPU, would set the
         # step time (cfg3: 17 tokens per image; cfg1: 65 tokens of width 192)
         if args.config == "cfg3":
@@ -320,6 +413,23 @@ def main():
         pcie = {"images_per_sec": round(world * B * n_it / tp, 2), "ms_per_step": round(1e3 * tp / n_it, 3),
                 "input": f"uint8 HWC {c['img']}x{c['img']}x3 from pinned host memory, async copy stream + device transform"}
 
+    # SPPP end to end (informational): the label maps are recomputed from the batch by the device SLIC in EVERY step
+    # (features + k-means + connectivity, ~10 launches) and copied into the buffer the replayed graph reads
+    slic_inc = None
+    if args.slic and args.config == "cfg3":
+        K.slic(images, n_segments=16, compactness=10.0)            # warm-up (lazy attributes, allocator)
+        sync()
+        ts0 = time.perf_counter()
+        for _ in range(args.steps):
+            segs.copy_(K.slic(images, n_segments=16, compactness=10.0))
+            step()
+        sync()
+        ts = time.perf_counter() - ts0
+        slic_inc = {"images_per_sec": round(world * B * args.steps / ts, 2), "ms_per_step": round(1e3 * ts / args.steps, 3),
+                    "what": "device SLIC (compactness 10, 16 segments) of the batch + the step, every step; synthetic "
+                            "N(0,1) images, so the superpixel-token count is not 16 for every image: the replayed graph "
+                            "was captured for 16 tokens and the timing, not the loss, is what this line reports"}
+
     # per-launch GEMM timing: two extra EAGER steps after the timed region (events cannot be captured in a graph).
     # Every rank runs them (the all-reduce inside opt.step() is collective); only rank 0 records events.
     trace, traced_steps, opt_ms = None, 0, None
@@ -360,6 +470,8 @@ def main():
             out["optimizer_and_allreduce_wait_ms"] = round(opt_ms, 3)
         if pcie is not None:
             out["pcie_inclusive"] = pcie
+        if slic_inc is not None:
+            out["slic_inclusive"] = slic_inc
         if trace:
             fam = {}
             for e0, e1, fl, key, shp, kern in trace:
@@ -374,22 +486,27 @@ def main():
             ach = fl / sec / 1e12
             # HBM bytes per launch come from committed PMC passes (rocprofv3 cannot run inside this process); they
             # are only reported while the kernel sources are the ones the profile was taken on.
-            traffic, stale = None, None
-            try:
-                with open(TRAFFIC_PROFILE) as f:
-                    prof = json.load(f)
-                if prof.get("config", "cfg2") == args.config and args.dtype == prof.get("dtype", "bf16"):
-                    traffic = prof["families"][dom]["hbm_bytes_per_launch"]
-                    stale = prof.get("csrc_sha16") != csrc_sha16()
-            except (OSError, KeyError, ValueError):
-                pass
+            traffic, stale, tsrc, tprof = None, None, None, None
+            found = traffic_profile(args.config, args.dtype)
+            if found is not None:
+                tsrc, tprof = found
+                stale = tprof.get("csrc_sha16") != csrc_sha16()
+                tags = {}
+                for t_ in trace:
+                    if t_[3] == dom:
+                        tags[t_[5]] = tags.get(t_[5], 0) + 1
+                tag = max(tags, key=tags.get)
+                traffic, _names = match_gemm_kernels(tprof, dom, tag)
+                if traffic is None and dom in tprof.get("families", {}):
+                    traffic = tprof["families"][dom]["hbm_bytes_per_launch"]
+                traffic = None if traffic is None else int(traffic)
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": traffic,
                                "kernel": f"gemm_{dom}", "launches": n, "avg_launch_us": round(1e6 * sec / n, 2),
                                "avg_flops_per_launch": round(fl / n, 1),
                                "measured": "HIP events around every launch of this kernel family in 2 un-timed steps after the timed region"}
             if traffic is not None:
-                out["roofline"]["traffic_source"] = os.path.relpath(TRAFFIC_PROFILE, ROOT)
+                out["roofline"]["traffic_source"] = os.path.relpath(tsrc, ROOT)
                 out["roofline"]["traffic_stale"] = bool(stale)      # true: csrc/ changed since the PMC passes were taken
                 gbps = traffic / (sec / n) / 1e9
                 out["roofline"]["hbm_view"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -399,6 +516,16 @@ def main():
                                         "tflops": round(v[1] / v[0] / 1e12, 1), "launches_per_step": v[2] // traced_steps}
                                     for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
             out["gemm_share_of_step"] = round(tot / traced_steps / (dt / args.steps), 3)
+            # What bounds the STEP: the HBM bytes all of its kernels move (PMC, same profile) against the 8 TB/s peak
+            # over the measured step time -- the step is HBM-bound as much as MFMA-bound.
+            if tprof is not None and tprof.get("hbm_bytes_per_step"):
+                hb = float(tprof["hbm_bytes_per_step"])
+                out["step_hbm"] = {"bytes_per_step": int(hb), "achieved": round(hb / (dt / args.steps) / 1e9, 1),
+                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": round(hb / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
+                                   "floor_ms_at_peak": round(hb / (HBM_PEAK_GBPS * 1e9) * 1e3, 3),
+                                   "source": os.path.relpath(tsrc, ROOT), "stale": bool(stale),
+                                   "what": "sum over every kernel of the step of (2*FETCH_SIZE + WRITE_SIZE) x launches"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, model, segs_np)
         print(json.dumps(out), flush=True)

@@ -87,6 +87,46 @@ class FlatBuffers:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
 
 
+class _Helper:
+    """The process-wide thread that issues host-staged (gloo) collectives of device buffers: it waits ON THE HOST for
+    the event recorded behind a bucket's last writer, then issues the all-reduce from an idle stream (see
+    GradSync._launch).  One thread for every GradSync of the process, FIFO: the order of collectives is the order of
+    the _launch calls, identical on all ranks."""
+    thread = None
+    queue = None
+    error = None
+
+    @classmethod
+    def ensure(cls, device):
+        if cls.thread is not None and cls.thread.is_alive():
+            return
+        import queue
+        cls.queue = queue.Queue()
+        cls.error = None
+
+        def run():
+            torch.cuda.set_device(device)
+            side = torch.cuda.Stream(device=device)
+            while True:
+                item = cls.queue.get()
+                try:
+                    if item is None:
+                        return
+                    sync, b, buf, ev = item
+                    ev.synchronize()                       # host wait: every writer of the slice has finished
+                    with torch.cuda.stream(side):
+                        h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=sync.group, async_op=True)
+                    sync._handles.append((h, buf))
+                    if _DEBUG:
+                        _dbg(f"issued sync#{id(sync) % 9973} bucket {b} thread {threading.current_thread().name}")
+                except BaseException as e:     # noqa: BLE001  (re-raised by GradSync.finish())
+                    cls.error = e
+                finally:
+                    cls.queue.task_done()
+        cls.thread = threading.Thread(target=run, name="favit-gradsync", daemon=True)
+        cls.thread.start()
+
+
 class GradSync:
     """Bucketed, overlapped all-reduce (mean) of a FlatBuffers' gradient buffer."""
 
@@ -189,6 +229,7 @@ class GradSync:
         self._seen = [dict() for _ in self.buckets]      # parameter index -> reported directly by the kernels?
         self._handles = []
         self._snap = []
+        self._queued = 0
 
     def _launch(self, b):
         if self._launched[b] or not self._active:
@@ -201,18 +242,48 @@ class GradSync:
         if _VERIFY:
             self._snap.append((b, buf.clone()))
         if self._host_staged and buf.is_cuda and not _NO_DRAIN:
-            # gloo stages device tensors through pinned host memory on pool streams that its worker threads
-            # synchronise.  With three or more ranks sharing ONE GPU (the only way to rehearse N ranks on a one-GPU
-            # box) such an op, issued while the compute stream still has work queued, intermittently never completes
-            # on any rank (identical launch sequences on all ranks: FAVIT_DP_DEBUG logs; gone with the stream drained
-            # first).  gloo is the rehearsal / test backend, so drain; nccl (RCCL) orders by stream events on the
-            # device and is launched without any host wait.
-            torch.cuda.current_stream().synchronize()
+            # gloo stages device tensors through pinned host memory: the op makes one of gloo's pool streams WAIT (on
+            # the device) for an event recorded on the calling thread's current stream -- here the compute stream, with
+            # the rest of backward queued behind it -- and a gloo worker thread blocks in a stream synchronise until the
+            # copy has run.  With several ranks sharing ONE GPU (the only way to rehearse N ranks on a one-GPU box)
+            # those device-side waits sit at the head of hardware queues of four processes at once and the box stops
+            # making progress: a 4-rank run without this block hung in its third step with, on EVERY rank, the main
+            # thread in wait() on the first bucket's handle, two threads in kfd_wait_on_events and two spinning on HSA
+            # signals (gloo's workers inside their stream synchronise), the network thread idle in epoll
+            # (gpurun_out/hang_rank*.txt, bench.py FAVIT_BENCH_WATCHDOG).  So no device-side wait is created: an event
+            # is recorded behind the bucket's last writer, a helper thread waits for it ON THE HOST and only then
+            # issues the collective, from an otherwise idle stream (gloo's own event is complete the moment it is
+            # recorded).  Buckets still go out while backward runs.  RCCL (one process per GPU, collectives ordered by
+            # stream events on its own stream) keeps the direct path below.
+            ev = torch.cuda.Event()
+            ev.record()
+            self._ensure_helper(buf.device)
+            self._queue.put((self, b, buf, ev))
+            self._queued += 1
+            return
         self._handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf))
+
+    def _ensure_helper(self, device):
+        _Helper.ensure(device)
+        self._queue = _Helper.queue
+
+    def _drain_helper(self):
+        """Every queued bucket has been issued (ONE helper thread per process: the collectives of all parameter
+        groups go out in the order of the _launch calls, which is the same on every rank)."""
+        if self._queued:
+            _Helper.queue.join()
+            self._queued = 0
+            if _Helper.error is not None:
+                e, _Helper.error = _Helper.error, None
+                raise e
 
     def abort(self):
         """A backward that raised may leave asynchronous all-reduces outstanding on slices of flat_g: wait for them
         (the buffer is about to be zeroed or reused) and forget the step's bookkeeping."""
+        try:
+            self._drain_helper()
+        except Exception:          # noqa: BLE001
+            pass
         for h, _ in self._handles:
             try:
                 h.wait()
@@ -248,6 +319,7 @@ class GradSync:
         if self._active:
             for b in range(len(self.buckets)):
                 self._launch(b)
+            self._drain_helper()
             for k, (h, _) in enumerate(self._handles):
                 if _DEBUG:
                     _dbg(f"wait sync#{id(self) % 9973} handle {k}/{len(self._handles)}")

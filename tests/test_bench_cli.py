@@ -39,12 +39,17 @@ def _check(j, steps, warmup, dtype="bf16"):
 
 
 @pytest.mark.parametrize("cfg,extra", [("cfg2", ["--batch", "16"]), ("cfg2", ["--batch", "16", "--dropout", "0.1"]),
-                                       ("cfg1", []), ("cfg3", ["--batch", "16"]),
+                                       ("cfg1", []), ("cfg3", ["--batch", "16"]), ("cfg3", ["--batch", "16", "--slic"]),
+                                       ("cfg5", ["--batch", "16"]), ("cfg2", ["--batch", "16", "--dtype", "fp32"]),
                                        ("cfg4", ["--batch", "2", "--dtype", "fp8"])])
 def test_bench_line(cfg, extra):
     j = _run("--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline", *extra)
-    _check(j, 3, 1, dtype="fp8" if "fp8" in extra else "bf16")
+    _check(j, 3, 1, dtype="fp8" if "fp8" in extra else "fp32" if "fp32" in extra else "bf16")
     assert j["config"]["baseline_config"] == cfg
+    if "--slic" in extra:
+        assert j["slic_inclusive"]["ms_per_step"] > j["ms_per_step"] and j["slic_inclusive"]["images_per_sec"] > 0
+    if cfg == "cfg5":
+        assert j["config"]["hip_graph"] is True and "R = 16 / R = 15" in j["config"]["workload"]
     if "--dropout" in extra:
         assert j["config"]["dropout"] == 0.1
 

@@ -6,7 +6,10 @@ their size (MI355X_MICROARCH.md), so bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB.
 The JSON is stamped with the fingerprint of csrc/ (the same one bench.py computes): bench.py only reports the
 traffic figure as current while the kernel sources are the ones the passes were taken on.
 
-usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <out.txt>"""
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <out.txt> [config] [dtype] [steps_profiled]
+
+The JSON also lists EVERY kernel of the profiled run (bytes per launch, launches per step), from which bench.py
+computes `step_hbm`: the HBM bytes one training step moves, against the 8 TB/s peak."""
 import csv, glob, hashlib, json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,6 +45,9 @@ def load(d, counter):
 
 def main():
     fd, wd, oj, ot = sys.argv[1:5]
+    config = sys.argv[5] if len(sys.argv) > 5 else "cfg2"
+    dtype = sys.argv[6] if len(sys.argv) > 6 else "bf16"
+    steps = int(sys.argv[7]) if len(sys.argv) > 7 else 3
     fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     rows = []
     for k in fe:
@@ -63,8 +69,13 @@ def main():
         head = None
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) -- python bench.py "
                          "--steps 2 --warmup 1; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE halves "
-                         "wide coalesced reads, MI355X_MICROARCH.md)", "config": "cfg2", "dtype": "bf16",
-               "csrc_sha16": csrc_sha16(), "git_head_when_folded": head, "families": fam}, open(oj, "w"), indent=1)
+                         "wide coalesced reads, MI355X_MICROARCH.md)", "config": config, "dtype": dtype,
+               "csrc_sha16": csrc_sha16(), "git_head_when_folded": head, "families": fam,
+               "steps_profiled": steps,
+               "kernels": [{"kernel": k[:120], "hbm_bytes_per_launch": int((2 * f + w) * 1024),
+                            "launches_per_step": round(n / steps, 3)} for k, n, f, w in rows],
+               "hbm_bytes_per_step": int(sum((2 * f + w) * 1024 * n for k, n, f, w in rows) / steps)},
+              open(oj, "w"), indent=1)
     with open(ot, "w") as o:
         o.write("HBM traffic per launch from rocprofv3 PMC (separate passes: --pmc FETCH_SIZE / --pmc WRITE_SIZE) over "
                 "`python bench.py --steps 2 --warmup 1`\nunits: counter value is KiB; per MI355X_MICROARCH.md FETCH_SIZE "
