@@ -89,7 +89,8 @@ _SIGS = {
     "favit_sppp_centroids": ([vp, vp, i32, i32, i32, vp], C.c_int),
     "favit_sppp_posenc_fwd": ([vp, vp, vp, i32, i32, i32, i32, vp], C.c_int),
     "favit_image_transform": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp], C.c_int),
-    "favit_slic_features": ([vp, vp, i32, i32, i32, f32, vp, vp], C.c_int),
+    "favit_slic_features_workspace": ([i32, i32, i32], C.c_int64),
+    "favit_slic_features": ([vp, vp, i32, i32, i32, f32, i32, vp, vp], C.c_int),
     "favit_slic_cluster_workspace": ([i32, i32], C.c_int64),
     "favit_slic_cluster": ([vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, vp, vp], C.c_int),
     "favit_slic_connect": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, vp], C.c_int),

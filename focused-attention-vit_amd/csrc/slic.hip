@@ -67,29 +67,38 @@ __global__ __launch_bounds__(1024) void slic_minmax_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void slic_features_kernel(const float* __restrict__ img, short* __restrict__ feat, int B,
-                                                            int H, int W, float sigma, int radius,
-                                                            const float* __restrict__ minmax) {
+// Gaussian weights of the separable pre-smoothing, computed once on the host (radius <= 32)
+struct BlurTaps { float w[65]; int radius; };
+
+// pass 1: horizontal blur of the three colour planes into tmp (fp32 [B,3,H,W]); radius 0: not launched
+__global__ __launch_bounds__(256) void slic_blur_x_kernel(const float* __restrict__ img, float* __restrict__ tmp, long n,
+                                                          int W, BlurTaps t) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W);
+  const float* row = img + (i - x);
+  float acc = 0.f;
+  for (int d = -t.radius; d <= t.radius; ++d) acc = fmaf(t.w[d + t.radius], row[reflect_idx(x + d, W)], acc);
+  tmp[i] = acc;
+}
+
+// pass 2: vertical blur (of tmp, or nothing when radius = 0), per-image min-max rescale, sRGB -> CIELAB, quantise
+__global__ __launch_bounds__(256) void slic_features_kernel(const float* __restrict__ src, short* __restrict__ feat, int B,
+                                                            int H, int W, BlurTaps t, const float* __restrict__ minmax) {
   const long p = (long)blockIdx.x * 256 + threadIdx.x;
   const long HW = (long)H * W;
   if (p >= (long)B * HW) return;
   const int b = (int)(p / HW);
   const int y = (int)((p - b * HW) / W), x = (int)((p - b * HW) % W);
-  const float* im = img + (long)b * 3 * HW;
+  const float* im = src + (long)b * 3 * HW;
   float rgb[3] = {0.f, 0.f, 0.f};
-  if (radius == 0) {
+  if (t.radius == 0) {
     for (int c = 0; c < 3; ++c) rgb[c] = im[c * HW + (long)y * W + x];
   } else {
-    float wsum = 0.f;
-    for (int k = -radius; k <= radius; ++k) wsum += __expf(-0.5f * k * k / (sigma * sigma));
-    for (int dy = -radius; dy <= radius; ++dy) {
-      const int yy = reflect_idx(y + dy, H);
-      const float wy = __expf(-0.5f * dy * dy / (sigma * sigma)) / wsum;
-      for (int dx = -radius; dx <= radius; ++dx) {
-        const int xx = reflect_idx(x + dx, W);
-        const float w = wy * (__expf(-0.5f * dx * dx / (sigma * sigma)) / wsum);
-        for (int c = 0; c < 3; ++c) rgb[c] = fmaf(w, im[c * HW + (long)yy * W + xx], rgb[c]);
-      }
+    for (int d = -t.radius; d <= t.radius; ++d) {
+      const long o = (long)reflect_idx(y + d, H) * W + x;
+      const float w = t.w[d + t.radius];
+      for (int c = 0; c < 3; ++c) rgb[c] = fmaf(w, im[c * HW + o], rgb[c]);
     }
   }
   if (minmax) {                      // image -= min; image /= (max - min)  unless the image is constant
@@ -170,68 +179,83 @@ __global__ __launch_bounds__(64) void slic_seed_kernel(const short* __restrict__
 // FAST (H, W <= 2047 and coef < 2^32, i.e. every real call): the five differences fit 24-bit multiplies (full rate;
 // v_mul_lo_u32 / v_mad_i64_i32 run at a quarter of it), the spatial and colour sums fit 32 bits and the distance is
 // ONE v_mad_u64_u32 -- the same integers as the 64-bit form, which stays for out-of-range arguments.
+// A workgroup of 256 threads owns 1024 consecutive pixels, four per thread (p = base + j*256 + tid: coalesced): the
+// four feature loads are in flight together and up to eight workgroups share a CU.  The first form, one pixel per
+// thread in 1024-thread workgroups (two per CU), spent its time in the serial chain centre load -> barrier -> pixel
+// load -> loop -> reduction -> barrier -> atomics of each workgroup: 163 us per iteration for 57 MB.
+constexpr int ASG_THREADS = 256, ASG_PPT = 4, ASG_TILE = ASG_THREADS * ASG_PPT;
 template <bool FAST>
-__global__ __launch_bounds__(SLIC_THREADS) void slic_assign_kernel(const short* __restrict__ feat, uint8_t* __restrict__ labels,
-                                                                   void* ws, int K, int H, int W, int step, long long coef) {
+__global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* __restrict__ feat, uint8_t* __restrict__ labels,
+                                                                  void* ws, int K, int H, int W, int step, long long coef) {
   __shared__ int cen[SLIC_MAXK][5];      // y16, x16, l, a, b
   __shared__ int sums[SLIC_MAXK][6];     // this workgroup's <= 1024 pixels: fits 32 bits
   const int b = blockIdx.y, tid = threadIdx.x;
   const int HW = H * W;
   const short* f = feat + (long)b * HW * 4;
   uint8_t* lab = labels + (long)b * HW;
-  if (tid < K * 5) cen[tid / 5][tid % 5] = slic_cen(ws, b, K)[tid];
-  if (tid < K * 6) sums[tid / 6][tid % 6] = 0;
+  for (int i = tid; i < K * 5; i += ASG_THREADS) cen[i / 5][i % 5] = slic_cen(ws, b, K)[i];
+  for (int i = tid; i < K * 6; i += ASG_THREADS) sums[i / 6][i % 6] = 0;
+  typedef __attribute__((ext_vector_type(4))) short short4_t;
+  short4_t qv[ASG_PPT];
+  int pp[ASG_PPT];
+#pragma unroll
+  for (int j = 0; j < ASG_PPT; ++j) {
+    pp[j] = blockIdx.x * ASG_TILE + j * ASG_THREADS + tid;
+    qv[j] = pp[j] < HW ? *reinterpret_cast<const short4_t*>(f + (long)pp[j] * 4) : (short4_t){0, 0, 0, 0};
+  }
   __syncthreads();
-  const int p = blockIdx.x * SLIC_THREADS + tid;
-  const bool live = p < HW;
-  int best_k = 255, y = 0, x = 0;
-  int q0 = 0, q1 = 0, q2 = 0;
-  if (live) {
-    y = p / W; x = p - y * W;
-    const short* q = f + (long)p * 4;
-    q0 = q[0]; q1 = q[1]; q2 = q[2];
-    unsigned long long best = ~0ull;
-    const unsigned coef32 = (unsigned)coef;
-    for (int k = 0; k < K; ++k) {
-      const int cy = cen[k][0] >> 4, cx = cen[k][1] >> 4;                 // int(centre), centres are >= 0
-      if (y < cy - 2 * step || y > cy + 2 * step || x < cx - 2 * step || x > cx + 2 * step) continue;
-      const int dy = 16 * y - cen[k][0], dx = 16 * x - cen[k][1];
-      const int dl = q0 - cen[k][2], da = q1 - cen[k][3], db = q2 - cen[k][4];
-      unsigned long long d;
-      if (FAST) {
-        const unsigned sp = (unsigned)__mul24(dy, dy) + (unsigned)__mul24(dx, dx);
-        const unsigned cq = (unsigned)__mul24(dl, dl) + (unsigned)__mul24(da, da) + (unsigned)__mul24(db, db);
-        d = (unsigned long long)coef32 * cq + sp;
-      } else {
-        // 32-bit differences, 32x32 -> 64-bit products: the same integers as 64-bit arithmetic throughout
-        const long long sp = (long long)dy * dy + (long long)dx * dx;
-        const long long cq = (long long)dl * dl + (long long)da * da + (long long)db * db;
-        d = (unsigned long long)(sp + coef * cq);
+  const unsigned coef32 = (unsigned)coef;
+#pragma unroll
+  for (int j = 0; j < ASG_PPT; ++j) {
+    const int p = pp[j];
+    const bool live = p < HW;
+    int best_k = 255, y = 0, x = 0;
+    const int q0 = qv[j][0], q1 = qv[j][1], q2 = qv[j][2];
+    if (live) {
+      y = p / W; x = p - y * W;
+      unsigned long long best = ~0ull;
+      for (int k = 0; k < K; ++k) {
+        const int cy = cen[k][0] >> 4, cx = cen[k][1] >> 4;                 // int(centre), centres are >= 0
+        if (y < cy - 2 * step || y > cy + 2 * step || x < cx - 2 * step || x > cx + 2 * step) continue;
+        const int dy = 16 * y - cen[k][0], dx = 16 * x - cen[k][1];
+        const int dl = q0 - cen[k][2], da = q1 - cen[k][3], db = q2 - cen[k][4];
+        unsigned long long d;
+        if (FAST) {
+          const unsigned sp = (unsigned)__mul24(dy, dy) + (unsigned)__mul24(dx, dx);
+          const unsigned cq = (unsigned)__mul24(dl, dl) + (unsigned)__mul24(da, da) + (unsigned)__mul24(db, db);
+          d = (unsigned long long)coef32 * cq + sp;
+        } else {
+          // 32-bit differences, 32x32 -> 64-bit products: the same integers as 64-bit arithmetic throughout
+          const long long sp = (long long)dy * dy + (long long)dx * dx;
+          const long long cq = (long long)dl * dl + (long long)da * da + (long long)db * db;
+          d = (unsigned long long)(sp + coef * cq);
+        }
+        if (d < best) { best = d; best_k = k; }
       }
-      if (d < best) { best = d; best_k = k; }
+      if (best_k == 255) best_k = lab[p];                                    // no window covers the pixel: keep
+      else lab[p] = (uint8_t)best_k;
     }
-    if (best_k == 255) best_k = lab[p];                                    // no window covers the pixel: keep
-    else lab[p] = (uint8_t)best_k;
-  }
-  // per-cluster sums: reduce over the lanes of the wave that share a cluster, one LDS atomic set per cluster
-  unsigned long long todo = __ballot(live);
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int kk = __shfl(best_k, leader, 64);
-    const bool in = live && best_k == kk;
-    const unsigned long long grp = __ballot(in);
-    const int s0 = masked_wave_sum(16 * y, in), s1 = masked_wave_sum(16 * x, in);
-    const int s2 = masked_wave_sum(q0, in), s3 = masked_wave_sum(q1, in), s4 = masked_wave_sum(q2, in);
-    const int cnt = __popcll(grp);
-    if ((tid & 63) == leader && kk < SLIC_MAXK) {
-      atomicAdd(&sums[kk][0], s0); atomicAdd(&sums[kk][1], s1); atomicAdd(&sums[kk][2], s2);
-      atomicAdd(&sums[kk][3], s3); atomicAdd(&sums[kk][4], s4); atomicAdd(&sums[kk][5], cnt);
+    // per-cluster sums: reduce over the lanes of the wave that share a cluster, one LDS atomic set per cluster
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int kk = __shfl(best_k, leader, 64);
+      const bool in = live && best_k == kk;
+      const unsigned long long grp = __ballot(in);
+      const int s0 = masked_wave_sum(16 * y, in), s1 = masked_wave_sum(16 * x, in);
+      const int s2 = masked_wave_sum(q0, in), s3 = masked_wave_sum(q1, in), s4 = masked_wave_sum(q2, in);
+      const int cnt = __popcll(grp);
+      if ((tid & 63) == leader && kk < SLIC_MAXK) {
+        atomicAdd(&sums[kk][0], s0); atomicAdd(&sums[kk][1], s1); atomicAdd(&sums[kk][2], s2);
+        atomicAdd(&sums[kk][3], s3); atomicAdd(&sums[kk][4], s4); atomicAdd(&sums[kk][5], cnt);
+      }
+      todo &= ~grp;
     }
-    todo &= ~grp;
   }
   __syncthreads();
-  if (tid < K * 6 && sums[tid / 6][tid % 6] != 0)
-    atomicAdd(reinterpret_cast<unsigned long long*>(slic_sums(ws, b, K)) + tid, (unsigned long long)(long long)sums[tid / 6][tid % 6]);
+  for (int i = tid; i < K * 6; i += ASG_THREADS)
+    if (sums[i / 6][i % 6] != 0)
+      atomicAdd(reinterpret_cast<unsigned long long*>(slic_sums(ws, b, K)) + i, (unsigned long long)(long long)sums[i / 6][i % 6]);
 }
 
 __global__ __launch_bounds__(64) void slic_update_kernel(void* ws, int K) {
@@ -267,11 +291,40 @@ __device__ __forceinline__ void cc_union(int* comp, int a, int b) {
   }
 }
 
-__global__ __launch_bounds__(256) void cc_init_kernel(int* __restrict__ comp, int* __restrict__ aux, int HW) {
-  const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-  if (p < HW) { comp[(long)b * HW + p] = p; aux[(long)b * HW + p] = 0; }
+// One workgroup per image row: comp[p] = first pixel of p's horizontal run of equal labels (an inclusive max-scan of
+// the run-start positions in LDS: no atomics, no pointer chasing), aux[p] = 0.  Replaces the per-pixel "comp[p] = p"
+// + union with the left neighbour (~50,000 atomicMin chains per image).
+__global__ __launch_bounds__(256) void cc_runs_kernel(const uint8_t* __restrict__ labels, int* __restrict__ comp_ws,
+                                                      int* __restrict__ aux_ws, int H, int W) {
+  __shared__ int start[2][256];
+  const int y = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const long base = (long)b * H * W + (long)y * W;
+  const uint8_t* lab = labels + base;
+  for (int x0 = 0; x0 < W; x0 += 256) {                        // rows wider than 256: chunks; a run crossing a chunk
+    const int x = x0 + tid;                                    // border starts again there (joined by cc_merge below)
+    int v = -1;
+    if (x < W) v = (tid == 0 || lab[x - 1] != lab[x]) ? x : -1;
+    start[0][tid] = v;
+    __syncthreads();
+    int cur = 0;
+    for (int o = 1; o < 256; o <<= 1) {
+      int m = start[cur][tid];
+      if (tid >= o) m = max(m, start[cur][tid - o]);
+      start[cur ^ 1][tid] = m;
+      cur ^= 1;
+      __syncthreads();
+    }
+    if (x < W) {
+      comp_ws[base + x] = y * W + start[cur][tid];
+      aux_ws[base + x] = 0;
+    }
+    __syncthreads();
+  }
 }
 
+// Unions across run borders only: (p, p - W) of equal label where p or p - W starts its run -- if neither does, the
+// pair (p - 1, p - W - 1) joins the same two runs -- and, for rows wider than one chunk, (p, p - 1) at chunk borders.
+// The root of a component is still its smallest pixel index whatever the order of the unions.
 __global__ __launch_bounds__(256) void cc_merge_kernel(const uint8_t* __restrict__ labels, int* __restrict__ comp_ws, int H, int W) {
   const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
   const int HW = H * W;
@@ -280,32 +333,51 @@ __global__ __launch_bounds__(256) void cc_merge_kernel(const uint8_t* __restrict
   int* comp = comp_ws + (long)b * HW;
   const int y = p / W, x = p - y * W;
   const uint8_t l = lab[p];
-  if (x > 0 && lab[p - 1] == l) cc_union(comp, p, p - 1);
-  if (y > 0 && lab[p - W] == l) cc_union(comp, p, p - W);
+  if (x > 0 && (x & 255) == 0 && lab[p - 1] == l) cc_union(comp, p, p - 1);
+  if (y > 0 && lab[p - W] == l) {
+    const bool s_here = x == 0 || (x & 255) == 0 || lab[p - 1] != l;
+    const bool s_up = x == 0 || (x & 255) == 0 || lab[p - W - 1] != l;
+    if (s_here || s_up) cc_union(comp, p, p - W);
+  }
 }
 
+// comp[p] = root; component sizes at the roots, one atomic per (wave, root) instead of one per pixel (64 consecutive
+// pixels belong to one to three components: ~50,000 atomics on a few dozen addresses per image before)
 __global__ __launch_bounds__(256) void cc_compress_kernel(int* __restrict__ comp_ws, int* __restrict__ aux_ws, int HW) {
   const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= HW) return;
+  const bool live = p < HW;
   int* comp = comp_ws + (long)b * HW;
-  const int r = cc_find(comp, p);
-  comp[p] = r;                                    // values only move toward the root: concurrent finds stay correct
-  atomicAdd(&aux_ws[(long)b * HW + r], 1);        // component sizes at the roots
+  int r = -1;
+  if (live) {
+    r = cc_find(comp, p);
+    comp[p] = r;                                  // values only move toward the root: concurrent finds stay correct
+  }
+  unsigned long long todo = __ballot(live);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int rr = __shfl(r, leader, 64);
+    const unsigned long long grp = __ballot(live && r == rr);
+    if ((threadIdx.x & 63) == leader) atomicAdd(&aux_ws[(long)b * HW + rr], __popcll(grp));
+    todo &= ~grp;
+  }
 }
 
 // per image: roots in raster order, consecutive labels for components >= min_size, a small component takes the label
 // of an already-labelled neighbour of its first pixel (x+1, x-1, y+1, y-1; the last one found wins).  Leaves the final
-// label of every component in aux[root].
+// label of every component in aux[root].  Everything the serial pass reads (component sizes, the ranks of the four
+// neighbour components) is gathered in parallel into LDS first: the pass itself touches no global memory (it used to
+// chase aux[] / comp[] through L2 once per component: 0.5 ms for 128 images).
 __global__ __launch_bounds__(SLIC_THREADS) void cc_relabel_kernel(const int* __restrict__ comp_ws, int* __restrict__ aux_ws,
                                                                   int* __restrict__ n_regions, int H, int W, int min_size) {
   __shared__ int n_roots;
-  __shared__ int root_px[SLIC_MAXC];     // unsorted roots
+  __shared__ int root_px[SLIC_MAXC];     // unsorted roots, then component sizes in rank order
   __shared__ int root_sorted[SLIC_MAXC]; // sorted by pixel index
   __shared__ int final_lab[SLIC_MAXC];
+  __shared__ short nb_rank[SLIC_MAXC][4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int HW = H * W;
   const int* comp = comp_ws + (long)b * HW;
-  int* aux = aux_ws + (long)b * HW;      // component sizes, then rank of a root, then its final label
+  int* aux = aux_ws + (long)b * HW;      // component sizes, then the final label of every root
   if (tid == 0) n_roots = 0;
   __syncthreads();
   for (int p = tid; p < HW; p += SLIC_THREADS) {
@@ -326,27 +398,41 @@ __global__ __launch_bounds__(SLIC_THREADS) void cc_relabel_kernel(const int* __r
     root_sorted[r] = root_px[i];
   }
   __syncthreads();
+  for (int r = tid; r < n; r += SLIC_THREADS) {
+    const int root = root_sorted[r];
+    root_px[r] = aux[root];                          // size (root_px is free after the sort)
+    const int y = root / W, x = root - y * W;
+    const int nb[4] = {x + 1 < W ? root + 1 : -1, x > 0 ? root - 1 : -1, y + 1 < H ? root + W : -1, y > 0 ? root - W : -1};
+    for (int i = 0; i < 4; ++i) {
+      int rk = -1;
+      if (nb[i] >= 0) {
+        const int ro = comp[nb[i]];
+        if (ro < root) {                             // labelled earlier: its rank by binary search of the sorted roots
+          int lo = 0, hi = n - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (root_sorted[mid] < ro) lo = mid + 1; else hi = mid;
+          }
+          rk = lo;
+        }
+      }
+      nb_rank[r][i] = (short)rk;
+    }
+  }
+  __syncthreads();
   if (tid == 0) {
     int next = 0;
     for (int r = 0; r < n; ++r) {
-      const int root = root_sorted[r];
-      const int sz = aux[root];          // sizes are read before the slot is reused for the rank
       int fl;
-      if (sz >= min_size) {
+      if (root_px[r] >= min_size) {
         fl = next++;
       } else {
         int adjacent = 0;
-        const int y = root / W, x = root - y * W;
-        const int nb[4] = {x + 1 < W ? root + 1 : -1, x > 0 ? root - 1 : -1, y + 1 < H ? root + W : -1, y > 0 ? root - W : -1};
-        for (int i = 0; i < 4; ++i) {
-          if (nb[i] < 0) continue;
-          const int ro = comp[nb[i]];
-          if (ro < root) adjacent = final_lab[aux[ro]];        // that component was labelled earlier (aux = its rank)
-        }
+        for (int i = 0; i < 4; ++i)
+          if (nb_rank[r][i] >= 0) adjacent = final_lab[nb_rank[r][i]];
         fl = adjacent;
       }
       final_lab[r] = fl;
-      aux[root] = r;
     }
     n_regions[b] = next;
   }
@@ -365,18 +451,39 @@ __global__ __launch_bounds__(256) void cc_output_kernel(const uint8_t* __restric
 
 }  // namespace
 
+extern "C" int64_t favit_slic_features_workspace(int32_t B, int32_t H, int32_t W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return (int64_t)sizeof(float) * (2 * (int64_t)B + 3 * (int64_t)B * H * W);    // min / max per image + the blur pass
+}
+
 extern "C" int favit_slic_features(const float* img, int16_t* feat, int32_t B, int32_t H, int32_t W, float sigma,
-                                   float* minmax, void* stream) {
-  if (!img || !feat || B <= 0 || H <= 0 || W <= 0 || sigma < 0.f) return FAVIT_ERR_INVALID;
-  const int radius = sigma > 0.f ? (int)(4.0f * sigma + 0.5f) : 0;
-  if (radius > 32) return FAVIT_ERR_UNSUPPORTED;
+                                   int32_t rescale, float* ws, void* stream) {
+  if (!img || !feat || !ws || B <= 0 || H <= 0 || W <= 0 || sigma < 0.f) return FAVIT_ERR_INVALID;
+  BlurTaps t;
+  t.radius = sigma > 0.f ? (int)(4.0f * sigma + 0.5f) : 0;
+  if (t.radius > 32) return FAVIT_ERR_UNSUPPORTED;
+  {
+    double wsum = 0.0;
+    for (int k = -t.radius; k <= t.radius; ++k) wsum += exp(-0.5 * k * k / ((double)sigma * sigma + (sigma > 0.f ? 0.0 : 1.0)));
+    for (int k = -t.radius; k <= t.radius; ++k)
+      t.w[k + t.radius] = (float)(exp(-0.5 * k * k / ((double)sigma * sigma + (sigma > 0.f ? 0.0 : 1.0))) / wsum);
+  }
+  hipStream_t st = as_stream(stream);
   const long n = (long)B * H * W;
+  float* minmax = rescale ? ws : nullptr;
+  float* tmp = ws + 2 * (long)B;
   if (minmax) {
-    hipLaunchKernelGGL(slic_minmax_kernel, dim3((unsigned)B), dim3(1024), 0, as_stream(stream), img, minmax, 3L * H * W);
+    hipLaunchKernelGGL(slic_minmax_kernel, dim3((unsigned)B), dim3(1024), 0, st, img, minmax, 3L * H * W);
     FAVIT_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(slic_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), img,
-                     reinterpret_cast<short*>(feat), B, H, W, sigma, radius, (const float*)minmax);
+  const float* src = img;
+  if (t.radius > 0) {
+    hipLaunchKernelGGL(slic_blur_x_kernel, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, st, img, tmp, 3 * n, W, t);
+    FAVIT_CHECK_LAUNCH();
+    src = tmp;
+  }
+  hipLaunchKernelGGL(slic_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
+                     reinterpret_cast<short*>(feat), B, H, W, t, (const float*)minmax);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }
@@ -397,13 +504,13 @@ extern "C" int favit_slic_cluster(const int16_t* feat, uint8_t* labels, const in
   if (hipMemsetAsync(labels, 0, (size_t)B * HW, st) != hipSuccess) return FAVIT_ERR_LAUNCH;
   hipLaunchKernelGGL(slic_seed_kernel, dim3((unsigned)B), dim3(64), 0, st, reinterpret_cast<const short*>(feat), init_yx, ws, K, H, W);
   FAVIT_CHECK_LAUNCH();
-  const dim3 grid((unsigned)((HW + SLIC_THREADS - 1) / SLIC_THREADS), (unsigned)B);
+  const dim3 grid((unsigned)((HW + ASG_TILE - 1) / ASG_TILE), (unsigned)B);
   for (int it = 0; it < iters; ++it) {
     if (H <= 2047 && W <= 2047 && coef < (1LL << 32))
-      hipLaunchKernelGGL(slic_assign_kernel<true>, grid, dim3(SLIC_THREADS), 0, st, reinterpret_cast<const short*>(feat), labels,
+      hipLaunchKernelGGL(slic_assign_kernel<true>, grid, dim3(ASG_THREADS), 0, st, reinterpret_cast<const short*>(feat), labels,
                          ws, K, H, W, step, (long long)coef);
     else
-      hipLaunchKernelGGL(slic_assign_kernel<false>, grid, dim3(SLIC_THREADS), 0, st, reinterpret_cast<const short*>(feat), labels,
+      hipLaunchKernelGGL(slic_assign_kernel<false>, grid, dim3(ASG_THREADS), 0, st, reinterpret_cast<const short*>(feat), labels,
                          ws, K, H, W, step, (long long)coef);
     FAVIT_CHECK_LAUNCH();
     hipLaunchKernelGGL(slic_update_kernel, dim3((unsigned)B), dim3(64), 0, st, ws, K);
@@ -419,7 +526,7 @@ extern "C" int favit_slic_connect(const uint8_t* labels, int32_t* ws_comp, int32
   hipStream_t st = as_stream(stream);
   const int HW = H * W;
   const dim3 grid((unsigned)((HW + 255) / 256), (unsigned)B);
-  hipLaunchKernelGGL(cc_init_kernel, grid, dim3(256), 0, st, ws_comp, ws_aux, HW);
+  hipLaunchKernelGGL(cc_runs_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), 0, st, labels, ws_comp, ws_aux, H, W);
   FAVIT_CHECK_LAUNCH();
   hipLaunchKernelGGL(cc_merge_kernel, grid, dim3(256), 0, st, labels, ws_comp, H, W);
   FAVIT_CHECK_LAUNCH();

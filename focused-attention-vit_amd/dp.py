@@ -87,44 +87,43 @@ class FlatBuffers:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
 
 
-class _Helper:
-    """The process-wide thread that issues host-staged (gloo) collectives of device buffers: it waits ON THE HOST for
-    the event recorded behind a bucket's last writer, then issues the all-reduce from an idle stream (see
-    GradSync._launch).  One thread for every GradSync of the process, FIFO: the order of collectives is the order of
-    the _launch calls, identical on all ranks."""
-    thread = None
-    queue = None
-    error = None
+class _Staged:
+    """Host-staged (gloo) collectives of device buffers, process-wide FIFO.  An entry is (sync, bucket, slice, event):
+    the event was recorded on the compute stream behind the slice's last writer.  pump() issues, in order, every
+    entry whose event has completed -- from an otherwise idle stream, so that gloo's own "wait for the caller's
+    stream" is satisfied the moment it is recorded and NO device-side wait is ever queued (see GradSync._launch for
+    what those waits did to a 4-rank rehearsal).  It is called from the thread that runs backward whenever a gradient
+    is reported, i.e. every few kernels; finish() pumps with block=True (host wait on the events).  One queue for all
+    parameter groups: the order of collectives is the order of the _launch calls, identical on every rank.  (A helper
+    thread doing the host waits was tried first: correct, but every hand-over of the interpreter lock to it costs the
+    5 ms switch interval while the main thread is busy launching kernels -- 179 ms per step instead of 66.)"""
+    pending = None
+    side = None
 
     @classmethod
-    def ensure(cls, device):
-        if cls.thread is not None and cls.thread.is_alive():
-            return
-        import queue
-        cls.queue = queue.Queue()
-        cls.error = None
+    def push(cls, item):
+        if cls.pending is None:
+            import collections
+            cls.pending = collections.deque()
+        cls.pending.append(item)
 
-        def run():
-            torch.cuda.set_device(device)
-            side = torch.cuda.Stream(device=device)
-            while True:
-                item = cls.queue.get()
-                try:
-                    if item is None:
-                        return
-                    sync, b, buf, ev = item
-                    ev.synchronize()                       # host wait: every writer of the slice has finished
-                    with torch.cuda.stream(side):
-                        h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=sync.group, async_op=True)
-                    sync._handles.append((h, buf))
-                    if _DEBUG:
-                        _dbg(f"issued sync#{id(sync) % 9973} bucket {b} thread {threading.current_thread().name}")
-                except BaseException as e:     # noqa: BLE001  (re-raised by GradSync.finish())
-                    cls.error = e
-                finally:
-                    cls.queue.task_done()
-        cls.thread = threading.Thread(target=run, name="favit-gradsync", daemon=True)
-        cls.thread.start()
+    @classmethod
+    def pump(cls, block=False):
+        q = cls.pending
+        while q:
+            sync, b, buf, ev = q[0]
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            q.popleft()
+            if cls.side is None or cls.side.device != buf.device:
+                cls.side = torch.cuda.Stream(device=buf.device)
+            with torch.cuda.stream(cls.side):
+                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=sync.group, async_op=True)
+            sync._handles.append((h, buf))
+            if _DEBUG:
+                _dbg(f"issued sync#{id(sync) % 9973} bucket {b}")
 
 
 class GradSync:
@@ -200,6 +199,8 @@ class GradSync:
         launch sequence that wrote the gradient itself; otherwise autograd's post-accumulate hook."""
         if self.defer:                 # graph capture / replay / no_sync(): finish() launches every bucket afterwards
             return
+        if self._host_staged and _Staged.pending:
+            _Staged.pump()             # staged buckets whose writers have finished meanwhile go out now
         b = self._bucket_of[i]
         prev = self._seen[b].get(i)
         if prev is not None:
@@ -229,7 +230,6 @@ class GradSync:
         self._seen = [dict() for _ in self.buckets]      # parameter index -> reported directly by the kernels?
         self._handles = []
         self._snap = []
-        self._queued = 0
 
     def _launch(self, b):
         if self._launched[b] or not self._active:
@@ -251,31 +251,20 @@ class GradSync:
             # thread in wait() on the first bucket's handle, two threads in kfd_wait_on_events and two spinning on HSA
             # signals (gloo's workers inside their stream synchronise), the network thread idle in epoll
             # (gpurun_out/hang_rank*.txt, bench.py FAVIT_BENCH_WATCHDOG).  So no device-side wait is created: an event
-            # is recorded behind the bucket's last writer, a helper thread waits for it ON THE HOST and only then
-            # issues the collective, from an otherwise idle stream (gloo's own event is complete the moment it is
-            # recorded).  Buckets still go out while backward runs.  RCCL (one process per GPU, collectives ordered by
+            # is recorded behind the bucket's last writer and the collective is issued only once that event has
+            # completed (polled from this thread at every reported gradient: _Staged), from an otherwise idle stream
+            # (gloo's own event is complete the moment it is recorded).  Buckets still go out while backward runs.  RCCL (one process per GPU, collectives ordered by
             # stream events on its own stream) keeps the direct path below.
             ev = torch.cuda.Event()
             ev.record()
-            self._ensure_helper(buf.device)
-            self._queue.put((self, b, buf, ev))
-            self._queued += 1
+            _Staged.push((self, b, buf, ev))
+            _Staged.pump()
             return
         self._handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf))
 
-    def _ensure_helper(self, device):
-        _Helper.ensure(device)
-        self._queue = _Helper.queue
-
     def _drain_helper(self):
-        """Every queued bucket has been issued (ONE helper thread per process: the collectives of all parameter
-        groups go out in the order of the _launch calls, which is the same on every rank)."""
-        if self._queued:
-            _Helper.queue.join()
-            self._queued = 0
-            if _Helper.error is not None:
-                e, _Helper.error = _Helper.error, None
-                raise e
+        """Every staged bucket of the process has been issued."""
+        _Staged.pump(block=True)
 
     def abort(self):
         """A backward that raised may leave asynchronous all-reduces outstanding on slices of flat_g: wait for them

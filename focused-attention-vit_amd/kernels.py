@@ -600,8 +600,9 @@ def slic(images, n_segments=16, compactness=0.1, sigma=1.0, max_num_iter=10, min
     out = torch.empty((B, H, W), dtype=torch.int64, device=dev)
     nreg = torch.empty(B, dtype=torch.int32, device=dev)
     L = _abi.lib()
-    mm = torch.empty((B, 2), dtype=torch.float32, device=dev) if rescale else None
-    _abi.check(L.favit_slic_features(_p(images), _p(feat), B, H, W, float(sigma), _p(mm), _st()), "favit_slic_features")
+    fws = torch.empty(int(L.favit_slic_features_workspace(B, H, W)) // 4, dtype=torch.float32, device=dev)
+    _abi.check(L.favit_slic_features(_p(images), _p(feat), B, H, W, float(sigma), int(bool(rescale)), _p(fws), _st()),
+               "favit_slic_features")
     cws = torch.empty(int(L.favit_slic_cluster_workspace(Kc, B)) // 8 + 1, dtype=torch.int64, device=dev)
     _abi.check(L.favit_slic_cluster(_p(feat), _p(lab), _p(init), Kc, B, H, W, step, coef, max_num_iter, _p(cws), _st()),
                "favit_slic_cluster")
@@ -628,9 +629,9 @@ def slic_stage_times(images, n_segments=16, compactness=0.1, sigma=1.0, max_num_
     nreg = torch.empty(B, dtype=torch.int32, device=dev)
     L = _abi.lib()
     cws = torch.empty(int(L.favit_slic_cluster_workspace(Kc, B)) // 8 + 1, dtype=torch.int64, device=dev)
-    mm = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    fws = torch.empty(int(L.favit_slic_features_workspace(B, H, W)) // 4, dtype=torch.float32, device=dev)
     stages = [
-        ("features", lambda: L.favit_slic_features(_p(images), _p(feat), B, H, W, float(sigma), _p(mm), _st())),
+        ("features", lambda: L.favit_slic_features(_p(images), _p(feat), B, H, W, float(sigma), 1, _p(fws), _st())),
         ("cluster", lambda: L.favit_slic_cluster(_p(feat), _p(lab), _p(init), Kc, B, H, W, step, coef, max_num_iter, _p(cws), _st())),
         ("connect", lambda: L.favit_slic_connect(_p(lab), _p(ws[0]), _p(ws[1]), _p(o), _p(nreg), B, H, W, min_size, _st())),
     ]

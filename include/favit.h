@@ -266,9 +266,11 @@ int favit_image_transform(const uint8_t* src, uint8_t* tmp, float* out, uint8_t*
  * published SLIC as skimage parametrises it, integer-exact after the colour conversion, and is checked against
  * the CPU restatement oracle/slic_oracle.py.
  *   features: img fp32 [B,3,H,W] -> feat int16 [B,H*W,4] = round(16 * CIELAB(gaussian_sigma(rescale(img)))) clamped to +-8191, lane 3 = 0;
- *             minmax: device workspace of 2*B floats -> every image is first rescaled to [0, 1] by its own minimum and
- *             maximum over all channels, as scikit-image >= 0.19 does before smoothing (the reference passes
- *             mean/std-normalised tensors, models/sppp_mhla.py:278); NULL = no rescale (scikit-image < 0.19)
+ *             rescale != 0: every image is first rescaled to [0, 1] by its own minimum and maximum over all channels,
+ *             as scikit-image >= 0.19 does before smoothing (the reference passes mean/std-normalised tensors,
+ *             models/sppp_mhla.py:278); 0 = no rescale (scikit-image < 0.19).  ws: device workspace of
+ *             favit_slic_features_workspace(B, H, W) bytes (min / max per image and the horizontal pass of the
+ *             separable gaussian)
  *   cluster : (feat values must lie in [-8191, 8191], as `features` produces them: the distance arithmetic relies on it)
  *             k-means, K <= 64 centres seeded at init_yx [K,2] (int32 y, x), window +-2*step, distance
  *             256*spatial^2 + coef*dq^2 (int64), `iters` rounds -> labels uint8 [B,H*W]; ws: 8-byte aligned device
@@ -277,8 +279,9 @@ int favit_image_transform(const uint8_t* src, uint8_t* tmp, float* out, uint8_t*
  *             consecutive labels from 0 -> out int64 [B,H*W]; n_regions int32 [B] (-1: more than 2048 components,
  *             out = the cluster map); ws_comp / ws_aux: int32 [B,H*W] workspaces.
  * ---------------------------------------------------------------------------------- */
-int favit_slic_features(const float* img, int16_t* feat, int32_t B, int32_t H, int32_t W, float sigma, float* minmax,
-                        void* stream);
+int64_t favit_slic_features_workspace(int32_t B, int32_t H, int32_t W);
+int favit_slic_features(const float* img, int16_t* feat, int32_t B, int32_t H, int32_t W, float sigma, int32_t rescale,
+                        float* ws, void* stream);
 int64_t favit_slic_cluster_workspace(int32_t K, int32_t B);
 int favit_slic_cluster(const int16_t* feat, uint8_t* labels, const int32_t* init_yx, int32_t K, int32_t B, int32_t H,
                        int32_t W, int32_t step, int64_t coef, int32_t iters, void* ws, void* stream);
