@@ -176,18 +176,25 @@ __global__ __launch_bounds__(64) void slic_seed_kernel(const short* __restrict__
   for (int c = 0; c < 6; ++c) sm[c] = 0;
 }
 
-// FAST (H, W <= 2047 and coef < 2^32, i.e. every real call): the five differences fit 24-bit multiplies (full rate;
-// v_mul_lo_u32 / v_mad_i64_i32 run at a quarter of it), the spatial and colour sums fit 32 bits and the distance is
-// ONE v_mad_u64_u32 -- the same integers as the 64-bit form, which stays for out-of-range arguments.
+// FAST (H, W <= 2047 and coef < 2^32, i.e. every real call): every difference fits 16 bits and every sum of squares 31
+// bits, so a candidate costs two packed subtractions, two v_dot2_i32_i16, one 24-bit multiply and ONE v_mad_u64_u32
+// (v_mul_lo_u32 / v_mad_i64_i32 of the general form run at a quarter of the VALU rate) -- the same integers as the 64-bit
+// form, which stays for out-of-range arguments.  The kernel is VALU-bound: ~11 of 16 centres pass the window test for
+// an average pixel of a 224 x 224 image (the 2 step x 2 step search window is part of the algorithm).
 // A workgroup of 256 threads owns 1024 consecutive pixels, four per thread (p = base + j*256 + tid: coalesced): the
 // four feature loads are in flight together and up to eight workgroups share a CU.  The first form, one pixel per
 // thread in 1024-thread workgroups (two per CU), spent its time in the serial chain centre load -> barrier -> pixel
 // load -> loop -> reduction -> barrier -> atomics of each workgroup: 163 us per iteration for 57 MB.
 constexpr int ASG_THREADS = 256, ASG_PPT = 4, ASG_TILE = ASG_THREADS * ASG_PPT;
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
 template <bool FAST>
 __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* __restrict__ feat, uint8_t* __restrict__ labels,
                                                                   void* ws, int K, int H, int W, int step, long long coef) {
   __shared__ int cen[SLIC_MAXK][5];      // y16, x16, l, a, b
+  // FAST form of a centre: packed 16-bit pairs (y16, x16) and (l, a), b, and the window origin (cy - 2 step, cx - 2 step):
+  // the differences are two v_pk_sub_i16, the two sums of squares two v_dot2_i32_i16 (every value fits 16 bits and
+  // every sum 31 bits for H, W <= 2047 and features within +-8191), the window test two unsigned compares
+  __shared__ __attribute__((aligned(16))) int cpk[SLIC_MAXK][8];
   __shared__ int sums[SLIC_MAXK][6];     // this workgroup's <= 1024 pixels: fits 32 bits
   const int b = blockIdx.y, tid = threadIdx.x;
   const int HW = H * W;
@@ -195,7 +202,18 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
   uint8_t* lab = labels + (long)b * HW;
   for (int i = tid; i < K * 5; i += ASG_THREADS) cen[i / 5][i % 5] = slic_cen(ws, b, K)[i];
   for (int i = tid; i < K * 6; i += ASG_THREADS) sums[i / 6][i % 6] = 0;
+  if (FAST) {
+    for (int k = tid; k < K; k += ASG_THREADS) {
+      const int* c = slic_cen(ws, b, K) + 5 * k;
+      cpk[k][0] = (c[0] & 0xffff) | (c[1] << 16);
+      cpk[k][1] = (c[2] & 0xffff) | (c[3] << 16);
+      cpk[k][2] = c[4];
+      cpk[k][3] = (c[0] >> 4) - 2 * step;
+      cpk[k][4] = (c[1] >> 4) - 2 * step;
+    }
+  }
   typedef __attribute__((ext_vector_type(4))) short short4_t;
+  typedef __attribute__((ext_vector_type(4))) int int4_t;
   short4_t qv[ASG_PPT];
   int pp[ASG_PPT];
 #pragma unroll
@@ -205,6 +223,7 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
   }
   __syncthreads();
   const unsigned coef32 = (unsigned)coef;
+  const unsigned win = 4u * (unsigned)step;
 #pragma unroll
   for (int j = 0; j < ASG_PPT; ++j) {
     const int p = pp[j];
@@ -214,23 +233,34 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
     if (live) {
       y = p / W; x = p - y * W;
       unsigned long long best = ~0ull;
-      for (int k = 0; k < K; ++k) {
-        const int cy = cen[k][0] >> 4, cx = cen[k][1] >> 4;                 // int(centre), centres are >= 0
-        if (y < cy - 2 * step || y > cy + 2 * step || x < cx - 2 * step || x > cx + 2 * step) continue;
-        const int dy = 16 * y - cen[k][0], dx = 16 * x - cen[k][1];
-        const int dl = q0 - cen[k][2], da = q1 - cen[k][3], db = q2 - cen[k][4];
-        unsigned long long d;
-        if (FAST) {
-          const unsigned sp = (unsigned)__mul24(dy, dy) + (unsigned)__mul24(dx, dx);
-          const unsigned cq = (unsigned)__mul24(dl, dl) + (unsigned)__mul24(da, da) + (unsigned)__mul24(db, db);
-          d = (unsigned long long)coef32 * cq + sp;
-        } else {
+      if (FAST) {
+        const s16x2_t pyx = {(short)(16 * y), (short)(16 * x)};
+        const s16x2_t pla = {(short)q0, (short)q1};
+        for (int k = 0; k < K; ++k) {
+          const int4_t c = *reinterpret_cast<const int4_t*>(&cpk[k][0]);
+          const int xlo = cpk[k][4];
+          // y in [cy - 2 step, cy + 2 step]  <=>  (unsigned)(y - (cy - 2 step)) <= 4 step
+          if ((unsigned)(y - c[3]) > win || (unsigned)(x - xlo) > win) continue;
+          const s16x2_t dyx = pyx - __builtin_bit_cast(s16x2_t, c[0]);
+          const s16x2_t dla = pla - __builtin_bit_cast(s16x2_t, c[1]);
+          const int db = q2 - c[2];
+          const unsigned sp = (unsigned)__builtin_amdgcn_sdot2(dyx, dyx, 0, false);
+          const unsigned cq = (unsigned)__builtin_amdgcn_sdot2(dla, dla, __mul24(db, db), false);
+          const unsigned long long d = (unsigned long long)coef32 * cq + sp;
+          if (d < best) { best = d; best_k = k; }
+        }
+      } else {
+        for (int k = 0; k < K; ++k) {
+          const int cy = cen[k][0] >> 4, cx = cen[k][1] >> 4;               // int(centre), centres are >= 0
+          if (y < cy - 2 * step || y > cy + 2 * step || x < cx - 2 * step || x > cx + 2 * step) continue;
           // 32-bit differences, 32x32 -> 64-bit products: the same integers as 64-bit arithmetic throughout
+          const int dy = 16 * y - cen[k][0], dx = 16 * x - cen[k][1];
+          const int dl = q0 - cen[k][2], da = q1 - cen[k][3], db = q2 - cen[k][4];
           const long long sp = (long long)dy * dy + (long long)dx * dx;
           const long long cq = (long long)dl * dl + (long long)da * da + (long long)db * db;
-          d = (unsigned long long)(sp + coef * cq);
+          const unsigned long long d = (unsigned long long)(sp + coef * cq);
+          if (d < best) { best = d; best_k = k; }
         }
-        if (d < best) { best = d; best_k = k; }
       }
       if (best_k == 255) best_k = lab[p];                                    // no window covers the pixel: keep
       else lab[p] = (uint8_t)best_k;
