@@ -70,7 +70,6 @@ struct KParams {
   int store_policy;    // cache policy of the epilogue's output stores (store16_policy)
   int rowsum_store;    // 1: a_rowsum is a private slab slot of this split (plain store), 0: atomicAdd
   int q_block0, q_tile0;   // p4: blocks >= q_block0 (> 0) run 64x128 quarter tiles of the full tiles from q_tile0 on
-  int prio;                // p4 (FAVIT_GEMM_PRIO): s_setprio of the main loop against the co-resident workgroup's epilogue
 #ifdef FAVIT_PROBE
   int dbg;     // probe build only (make probe; tools/): 1 = skip epilogue, 2 = skip main loop
   unsigned long long* probe;   // probe build only: per-wave cycle stamps of the pp kernel (favit_probe_buffer)
@@ -996,9 +995,6 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
     sb += b_step;
   };
 
-  if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
-  else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
-  else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
   if (nk > 0) issue(0);
   if (nk > 1) issue(1);
   int cur = 0;
@@ -1066,7 +1062,6 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
     if (p.scale_b) alpha *= p.scale_b[0];
   }
   __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
-  if (p.prio) __builtin_amdgcn_s_setprio(0);
 #ifdef FAVIT_PROBE
   if (tl) tl1 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -2094,7 +2089,7 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 // Kernel-selection switches (tools/README.md), read once per process.  Every selectable kernel computes the
 // same result; the work-skipping probe switch (FAVIT_GEMM_DBG) exists only in the `make probe` build.
 struct GemmKnobs {
-  int dbg, store_policy, prio;
+  int dbg, store_policy;
   bool force128, no_p4, no_p7, no_s64, no_pp, no_quarter;
   long quarter_max;
   GemmKnobs() {
@@ -2105,7 +2100,6 @@ struct GemmKnobs {
     dbg = 0;
 #endif
     store_policy = (e = getenv("FAVIT_GEMM_STORE")) ? atoi(e) : 1;
-    prio = (e = getenv("FAVIT_GEMM_PRIO")) ? atoi(e) : 0;
     force128 = getenv("FAVIT_GEMM_TILE128") != nullptr;
     no_p4 = getenv("FAVIT_GEMM_NO_P4") != nullptr;
     no_p7 = getenv("FAVIT_GEMM_NO_P7") != nullptr;
@@ -2217,7 +2211,6 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.xcd_split = 0;
   kp.q_block0 = 0;
   kp.q_tile0 = 0;
-  kp.prio = knobs().prio;
   kp.alpha = g->alpha;
   kp.scale_a = fp8 ? g->scale_a : nullptr;
   kp.scale_b = fp8 ? g->scale_b : nullptr;
@@ -2473,8 +2466,7 @@ int grouped_tn_impl(const favit_gemm_t* gs, int32_t count, float* ws, int64_t ws
     kp.store_policy = 0;
     kp.rowsum_store = 0;
     kp.q_block0 = kp.q_tile0 = 0;
-    kp.prio = knobs().prio;
-    kp.scale_a = kp.scale_b = nullptr;
+      kp.scale_a = kp.scale_b = nullptr;
 #ifdef FAVIT_PROBE
     kp.dbg = knobs().dbg;            // probe build: FAVIT_GEMM_DBG=1 times the grouped main loop without its epilogue
     kp.probe = nullptr;

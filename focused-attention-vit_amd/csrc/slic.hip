@@ -213,7 +213,6 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
     }
   }
   typedef __attribute__((ext_vector_type(4))) short short4_t;
-  typedef __attribute__((ext_vector_type(4))) int int4_t;
   short4_t qv[ASG_PPT];
   int pp[ASG_PPT];
 #pragma unroll
@@ -237,13 +236,12 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
         const s16x2_t pyx = {(short)(16 * y), (short)(16 * x)};
         const s16x2_t pla = {(short)q0, (short)q1};
         for (int k = 0; k < K; ++k) {
-          const int4_t c = *reinterpret_cast<const int4_t*>(&cpk[k][0]);
-          const int xlo = cpk[k][4];
+          const int c_yx = cpk[k][0], c_la = cpk[k][1], c_b = cpk[k][2], ylo = cpk[k][3], xlo = cpk[k][4];
           // y in [cy - 2 step, cy + 2 step]  <=>  (unsigned)(y - (cy - 2 step)) <= 4 step
-          if ((unsigned)(y - c[3]) > win || (unsigned)(x - xlo) > win) continue;
-          const s16x2_t dyx = pyx - __builtin_bit_cast(s16x2_t, c[0]);
-          const s16x2_t dla = pla - __builtin_bit_cast(s16x2_t, c[1]);
-          const int db = q2 - c[2];
+          if ((unsigned)(y - ylo) > win || (unsigned)(x - xlo) > win) continue;
+          const s16x2_t dyx = pyx - __builtin_bit_cast(s16x2_t, c_yx);
+          const s16x2_t dla = pla - __builtin_bit_cast(s16x2_t, c_la);
+          const int db = q2 - c_b;
           const unsigned sp = (unsigned)__builtin_amdgcn_sdot2(dyx, dyx, 0, false);
           const unsigned cq = (unsigned)__builtin_amdgcn_sdot2(dla, dla, __mul24(db, db), false);
           const unsigned long long d = (unsigned long long)coef32 * cq + sp;

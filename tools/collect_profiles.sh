@@ -1,22 +1,54 @@
 #!/bin/bash
-# Profiles judged under profiles/: kernel-time stats of the benchmark command for cfg2 (headline), cfg1 (dense
-# attention) and cfg3 (SPPP), and separate PMC passes (HBM bytes, SQ wave states) for cfg2.  Run on the GPU box:
-#   gpurun -- bash tools/collect_profiles.sh r02
+# Profiles judged under profiles/ (run on the GPU box:  gpurun -- bash tools/collect_profiles.sh r03):
+#   * kernel-time stats of the benchmark command for every configuration (cfg2 = headline; cfg1, cfg3, cfg4 bf16 / fp8,
+#     cfg5; cfg2 in fp32 -- the precision at which the north star's 1e-3 logit tolerance holds);
+#   * separate PMC passes (never combined with a trace domain): FETCH_SIZE and WRITE_SIZE per configuration, folded by
+#     tools/pmc_traffic.py into HBM bytes per launch and per step; one SQ / GRBM pass for cfg2 (MFMA-pipe utilisation).
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
+prof=$root/profiles
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-for cfg in cfg2 cfg1 cfg3; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$cfg -- python3 $root/bench.py --config $cfg \
-    --steps 12 --warmup 3 --no-cpu-baseline > $out/bench_$cfg.json 2> $out/bench_$cfg.err || echo "stats $cfg failed"
-done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --steps 2 --warmup 1 \
-  --no-cpu-baseline --no-gemm-trace > /dev/null 2> $out/pmc_fetch.err || echo "pmc fetch failed"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py --steps 2 --warmup 1 \
-  --no-cpu-baseline --no-gemm-trace > /dev/null 2> $out/pmc_write.err || echo "pmc write failed"
+run_stats() {   # name, bench args...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_$name -- python3 $root/bench.py "$@" \
+    --steps 12 --warmup 3 --no-cpu-baseline > $out/bench_$name.json 2> $out/bench_$name.err || echo "stats $name failed"
+  find $out/stats_$name -name "*kernel_trace.csv" -delete
+  local st=$(find $out/stats_$name -name "*kernel_stats.csv" | head -1)
+  [ -n "$st" ] && cp $st $prof/${tag}_bench_kernel_stats_$name.csv
+  grep '^{' $out/bench_$name.json > $prof/${tag}_bench_under_rocprof_$name.json || true
+  echo "[collect] stats $name done"
+}
+run_pmc() {     # name, config, dtype, bench args...
+  local name=$1 cfg=$2 dt=$3; shift 3
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$name -- python3 $root/bench.py "$@" --steps 2 --warmup 1 \
+    --no-cpu-baseline --no-gemm-trace > /dev/null 2> $out/pmc_fetch_$name.err || echo "pmc fetch $name failed"
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$name -- python3 $root/bench.py "$@" --steps 2 --warmup 1 \
+    --no-cpu-baseline --no-gemm-trace > /dev/null 2> $out/pmc_write_$name.err || echo "pmc write $name failed"
+  python3 $root/tools/pmc_traffic.py $out/pmc_fetch_$name $out/pmc_write_$name $prof/${tag}_pmc_hbm_traffic_$name.json \
+    $prof/${tag}_pmc_hbm_traffic_$name.txt $cfg $dt 3 || echo "fold $name failed"
+  rm -rf $out/pmc_fetch_$name $out/pmc_write_$name
+  echo "[collect] pmc $name done"
+}
+run_stats cfg2 --config cfg2
+run_pmc cfg2 cfg2 bf16 --config cfg2
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
   --output-format csv -d $out/pmc_sq -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-trace \
   > /dev/null 2> $out/pmc_sq.err || echo "pmc sq failed"
-find $out -name "*kernel_stats.csv" | head
+python3 $root/tools/pmc_mfma.py $out/pmc_sq $prof/${tag}_pmc_bench_sq.txt > /dev/null 2>&1 || echo "sq fold failed"
+rm -rf $out/pmc_sq
+echo "[collect] sq done"
+run_stats cfg2_fp32 --config cfg2 --dtype fp32
+run_stats cfg4_bf16 --config cfg4
+run_pmc cfg4_bf16 cfg4 bf16 --config cfg4
+run_stats cfg4_fp8 --config cfg4 --dtype fp8
+run_pmc cfg4_fp8 cfg4 fp8 --config cfg4 --dtype fp8
+run_stats cfg1 --config cfg1
+run_pmc cfg1 cfg1 bf16 --config cfg1
+run_stats cfg3 --config cfg3 --slic
+run_pmc cfg3 cfg3 bf16 --config cfg3
+run_stats cfg5 --config cfg5
+run_pmc cfg5 cfg5 bf16 --config cfg5
+ls -la $prof | tail -40
