@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void slic_seed_kernel(const short* __restrict__
 // four feature loads are in flight together and up to eight workgroups share a CU.  The first form, one pixel per
 // thread in 1024-thread workgroups (two per CU), spent its time in the serial chain centre load -> barrier -> pixel
 // load -> loop -> reduction -> barrier -> atomics of each workgroup: 163 us per iteration for 57 MB.
-constexpr int ASG_THREADS = 256, ASG_PPT = 4, ASG_TILE = ASG_THREADS * ASG_PPT;
+constexpr int ASG_THREADS = 256, ASG_PPT = 4, ASG_ROUNDS = 4, ASG_TILE = ASG_THREADS * ASG_PPT * ASG_ROUNDS;
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
 template <bool FAST>
 __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* __restrict__ feat, uint8_t* __restrict__ labels,
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
   // the differences are two v_pk_sub_i16, the two sums of squares two v_dot2_i32_i16 (every value fits 16 bits and
   // every sum 31 bits for H, W <= 2047 and features within +-8191), the window test two unsigned compares
   __shared__ __attribute__((aligned(16))) int cpk[SLIC_MAXK][8];
-  __shared__ int sums[SLIC_MAXK][6];     // this workgroup's <= 1024 pixels: fits 32 bits
+  __shared__ int sums[SLIC_MAXK][6];     // this workgroup's <= 4096 pixels: 16 * 2047 * 4096 fits 32 bits
   const int b = blockIdx.y, tid = threadIdx.x;
   const int HW = H * W;
   const short* f = feat + (long)b * HW * 4;
@@ -213,16 +213,20 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
     }
   }
   typedef __attribute__((ext_vector_type(4))) short short4_t;
+  const unsigned coef32 = (unsigned)coef;
+  const unsigned win = 4u * (unsigned)step;
+  __syncthreads();
+  // ASG_ROUNDS rounds of ASG_PPT pixels per thread: the per-cluster sums of 4096 pixels leave the workgroup as ONE set of
+  // 64-bit global atomics (every workgroup of an image adds to the same K x 6 addresses: with 1024 pixels per
+  // workgroup those contended atomics were a third of the kernel)
+  for (int rnd = 0; rnd < ASG_ROUNDS; ++rnd) {
   short4_t qv[ASG_PPT];
   int pp[ASG_PPT];
 #pragma unroll
   for (int j = 0; j < ASG_PPT; ++j) {
-    pp[j] = blockIdx.x * ASG_TILE + j * ASG_THREADS + tid;
+    pp[j] = blockIdx.x * ASG_TILE + (rnd * ASG_PPT + j) * ASG_THREADS + tid;
     qv[j] = pp[j] < HW ? *reinterpret_cast<const short4_t*>(f + (long)pp[j] * 4) : (short4_t){0, 0, 0, 0};
   }
-  __syncthreads();
-  const unsigned coef32 = (unsigned)coef;
-  const unsigned win = 4u * (unsigned)step;
 #pragma unroll
   for (int j = 0; j < ASG_PPT; ++j) {
     const int p = pp[j];
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
       todo &= ~grp;
     }
   }
+  }   // rounds
   __syncthreads();
   for (int i = tid; i < K * 6; i += ASG_THREADS)
     if (sums[i / 6][i % 6] != 0)

@@ -524,8 +524,13 @@ def lin_bwd_w(dy, a, M, N, Kd, want_bias=True, wp=None, bp=None, allow_fp8=True)
                             [p for p, t in ((wp, tw), (bp, tb)) if t is not None]))
         return (None if tw is not None else dw), (None if tb is not None else db)
     with _side_stream(dy, a, dw, db):
-        K.gemm(dy, a, dw, N, Kd, M, N, Kd, Kd, a_kmajor=False, b_kmajor=False, a_rowsum=db,
-               accumulate=tw is not None)
+        # a long-token weight gradient outside a block (patch embedding: 50,176 tokens at cfg2): the grouped launch
+        # with ONE problem -- K-splits into slabs + fixed-order reduction -- instead of split-K with fp32 atomics
+        # (73 -> ~45 us, and bitwise reproducible); it declines what it cannot take (short or ragged token counts)
+        if not (dy.dtype == torch.bfloat16 and M >= 8192 and (db is not None or not want_bias) and
+                K.gemm_grouped_tn([(dy, a, dw, db, tw is not None)])):
+            K.gemm(dy, a, dw, N, Kd, M, N, Kd, Kd, a_kmajor=False, b_kmajor=False, a_rowsum=db,
+                   accumulate=tw is not None)
     if tw is not None:
         _ready(wp)
     if tb is not None:
