@@ -60,7 +60,6 @@ _SIGS = {
     "favit_gemm_grouped_tn_workspace": ([C.POINTER(GemmDesc), i32], C.c_int64),
     "favit_gemm_grouped_tn_ws": ([C.POINTER(GemmDesc), i32, vp, i64, vp], C.c_int),
     "favit_cast": ([vp, C.c_int, vp, C.c_int, i64, vp], C.c_int),
-    "favit_gemm_residual_ln": ([vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, i32, i64, f32, vp], C.c_int),
     "favit_fp8_amax": ([vp, C.c_int, i64, i64, i64, vp, vp], C.c_int),
     "favit_fp8_quantize": ([vp, C.c_int, i64, i64, i64, vp, i64, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp], C.c_int),
     "favit_layernorm_fwd": ([vp, i64, vp, vp, vp, C.c_int, vp, vp, i64, i32, f32, vp], C.c_int),

@@ -1512,223 +1512,6 @@ int launch_p7(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
 }
 
 // --------------------------------------------------------------------------------------
-// bf16 kernel "wn": 256 x 384 tile = WHOLE ROWS of an N = 384 output, so that the epilogue of the projection / fc2
-// GEMM can do what the next kernel would: y = A.W^T + bias + residual (the fp32 residual stream) AND its LayerNorm
-// (mean, rstd, bf16 normalised copy) -- the stand-alone ln_fwd pass (read 77 MB, write 39 MB per call at cfg2) is gone.
-// Eight waves as 4 (rows) x 2 (columns), 64 x 192 each = 48 accumulator tiles (192 VGPRs): one workgroup per CU, two
-// waves per SIMD.  BK = 32, three 40-KiB stages (A 16 KiB + W 24 KiB), five DMA pieces per wave and stage.  Operand
-// bytes per flop are 56 % of the 256x128 tile's.  The W fragments are read with a row permutation (tile 4q+s covers
-// columns 64q + 16(m/4) + 4s + m%4) so that a lane ends up with 16 CONSECUTIVE columns per group q: 64-byte fp32 and
-// 32-byte bf16 stores straight from the accumulators, no LDS transpose.  Row statistics: lane-local sums over 48
-// values, two shuffles across the lane groups, one LDS exchange between the two column waves; mean first, centred
-// squares second (two barriers), as the stand-alone kernel computes them.
-// --------------------------------------------------------------------------------------
-constexpr int WN_N = 384;
-constexpr int WN_THREADS = 512;
-constexpr int WN_A_BYTES = 256 * 64;                 // 16 KiB
-constexpr int WN_B_BYTES = WN_N * 64;                // 24 KiB
-constexpr int WN_STAGE = WN_A_BYTES + WN_B_BYTES;    // 40 KiB
-constexpr int WN_LDS = 3 * WN_STAGE;                 // 122880
-
-struct WnParams {
-  const bf16_t* A; long lda;
-  const bf16_t* W; long ldw;
-  const float* bias;
-  const float* residual; long ld_res;
-  float* x_out; long ldx;
-  const float* gamma; const float* beta;
-  bf16_t* xn_out;                                    // [M, 384] contiguous
-  float* mean; float* rstd;
-  long M, K;
-  float eps;
-  int dbg;                                           // probe build: 1 = main loop only (timing)
-};
-
-__global__ __launch_bounds__(WN_THREADS, 2) void gemm_bf16_wn_ln_kernel(WnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int g = lane >> 4, c = lane & 15;
-  const long m0 = (long)blockIdx.x * 256;
-  const int nk = (int)(p.K / P4_BK);
-
-  f32x4 acc[4][12];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int t = 0; t < 12; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // DMA: wave w moves A pieces 2w, 2w+1 (16 rows each) and W pieces 3w .. 3w+2
-  const char* sa[2];
-  const char* sb[3];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) sa[j] = reinterpret_cast<const char*>(glds_src32<true>(p.A, p.lda, m0, p.M, 0, 2 * wave + j, lane));
-#pragma unroll
-  for (int j = 0; j < 3; ++j) sb[j] = reinterpret_cast<const char*>(glds_src32<true>(p.W, p.ldw, 0, WN_N, 0, 3 * wave + j, lane));
-  auto issue = [&](int buf) {
-    char* st = smem + buf * WN_STAGE;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + (2 * wave + j) * 1024), 16, 0, 0);
-      sa[j] += 64;
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)sb[j], (lptr_t)(st + WN_A_BYTES + (3 * wave + j) * 1024), 16, 0, 0);
-      sb[j] += 64;
-    }
-  };
-  if (nk > 0) issue(0);
-  if (nk > 1) issue(1);
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);
-    const char* st = smem + cur * WN_STAGE;
-    const char* lb = st + WN_A_BYTES;
-    bf16x8 af[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = load_frag32<true>(st, wr * 64 + i * 16, lane);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      bf16x8 bfr[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) bfr[s4] = load_frag32<true>(lb, wc * 192 + (4 * q + s4) * 16, lane);
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          acc[i][4 * q + s4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[s4], af[i], acc[i][4 * q + s4], 0, 0, 0);
-    }
-    cur = cur == 2 ? 0 : cur + 1;
-  }
-#ifdef FAVIT_PROBE
-  if (p.dbg == 1) {
-    float sdbg = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int t = 0; t < 12; ++t) sdbg += acc[i][t][0] + acc[i][t][1] + acc[i][t][2] + acc[i][t][3];
-    if (sdbg == 12345.678f) p.x_out[0] = sdbg;
-    return;
-  }
-#endif
-  __syncthreads();                                    // stage buffers are free
-  // LDS after the loop: [0, 4 KiB) statistics exchange [2 passes][2 wc][256 rows]; then one 16-row x 192-column fp32
-  // scratch per wave (row stride 196 floats: the accumulator layout and the row-linear layout are both conflict-free)
-  float* part = reinterpret_cast<float*>(smem);
-  constexpr int WS_LD = 196;
-  float* ws = reinterpret_cast<float*>(smem + 4096) + wave * (16 * WS_LD);
-  const long mw = m0 + wr * 64;                       // first row of this wave
-  const int nw = wc * 192;                            // first column of this wave
-  // Global traffic goes through the scratch in ROW-LINEAR order (a wave-instruction covers 1,024 contiguous bytes of
-  // a 768-byte row segment and the start of the next): accumulator-layout loads / stores would touch 16 rows x 64 B
-  // per instruction (measured: the whole epilogue 150 us instead of ~40).
-  // lane l of row-linear instruction k handles chunk ch = 64k + l: row ch / 48, columns 4 (ch % 48) .. +3
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    asm volatile("" ::: "memory");                    // bias (and gamma / beta below) are re-read per row group: kept in
-                                                      // registers across the unrolled groups they cost 48-96 VGPRs (spills)
-    // residual block -> scratch (row-linear, coalesced)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {                  // four rows x 256 contiguous bytes per wave-instruction
-      long m = mw + 16 * i + 4 * rg + g;
-      m = m < p.M ? m : p.M - 1;
-      const float* src = p.residual + m * p.ld_res + nw + 4 * c;
-      float* dst = ws + (4 * rg + g) * WS_LD + 4 * c;
-#pragma unroll
-      for (int ct = 0; ct < 3; ++ct)
-        *reinterpret_cast<float4*>(dst + 64 * ct) = *reinterpret_cast<const float4*>(src + 64 * ct);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 12; ++t) {
-      const int n = 16 * t + 4 * g;
-      const float4 rv = *reinterpret_cast<const float4*>(ws + c * WS_LD + n);
-      const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + nw + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      f32x4& a = acc[i][t];
-      a[0] += bv.x + rv.x; a[1] += bv.y + rv.y; a[2] += bv.z + rv.z; a[3] += bv.w + rv.w;
-      sum += (a[0] + a[1]) + (a[2] + a[3]);
-    }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    if (g == 0) part[wc * 256 + wr * 64 + 16 * i + c] = sum;
-  }
-  __syncthreads();
-  float mu[4], rs[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wr * 64 + 16 * i + c;
-    mu[i] = (part[r] + part[256 + r]) * (1.0f / (float)WN_N);
-    float sq = 0.f;
-#pragma unroll
-    for (int t = 0; t < 12; ++t) {
-      const f32x4& a = acc[i][t];
-      const float d0 = a[0] - mu[i], d1 = a[1] - mu[i], d2 = a[2] - mu[i], d3 = a[3] - mu[i];
-      sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-    }
-    sq += __shfl_xor(sq, 16);
-    sq += __shfl_xor(sq, 32);
-    if (g == 0) part[512 + wc * 256 + r] = sq;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wr * 64 + 16 * i + c;
-    rs[i] = rsqrtf((part[512 + r] + part[768 + r]) * (1.0f / (float)WN_N) + p.eps);
-    if (g == 0 && wc == 0 && m0 + r < p.M) { p.mean[m0 + r] = mu[i]; p.rstd[m0 + r] = rs[i]; }
-  }
-  bf16_t* wsb = reinterpret_cast<bf16_t*>(ws);        // the same scratch as 16 x 192 bf16 (row stride 392 elements)
-  constexpr int WSB_LD = 2 * WS_LD;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    asm volatile("" ::: "memory");
-    // x: accumulator layout -> scratch -> row-linear stores
-#pragma unroll
-    for (int t = 0; t < 12; ++t)
-      *reinterpret_cast<f32x4*>(ws + c * WS_LD + 16 * t + 4 * g) = acc[i][t];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const long m = mw + 16 * i + 4 * rg + g;
-      const float* src = ws + (4 * rg + g) * WS_LD + 4 * c;
-      float* dst = p.x_out + m * p.ldx + nw + 4 * c;
-      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-#pragma unroll
-      for (int ct = 0; ct < 3; ++ct) {
-        const u32x4 raw = *reinterpret_cast<const u32x4*>(src + 64 * ct);
-        if (m < p.M) __builtin_nontemporal_store(raw, reinterpret_cast<u32x4*>(dst + 64 * ct));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // LayerNorm output: accumulator layout -> scratch (bf16) -> row-linear 16-byte stores (24 chunks per row)
-#pragma unroll
-    for (int t = 0; t < 12; ++t) {
-      const int n = 16 * t + 4 * g;
-      const float4 gv = *reinterpret_cast<const float4*>(p.gamma + nw + n);
-      const float4 bv = *reinterpret_cast<const float4*>(p.beta + nw + n);
-      const f32x4& a = acc[i][t];
-      bf16x4 y = {(bf16_t)((a[0] - mu[i]) * rs[i] * gv.x + bv.x), (bf16_t)((a[1] - mu[i]) * rs[i] * gv.y + bv.y),
-                  (bf16_t)((a[2] - mu[i]) * rs[i] * gv.z + bv.z), (bf16_t)((a[3] - mu[i]) * rs[i] * gv.w + bv.w)};
-      *reinterpret_cast<bf16x4*>(wsb + c * WSB_LD + n) = y;
-    }
-#pragma unroll
-    for (int rg = 0; rg < 2; ++rg) {                  // eight rows x 128 contiguous bytes per wave-instruction
-      const int row = 8 * rg + (lane >> 3), cc = lane & 7;
-      const long m = mw + 16 * i + row;
-#pragma unroll
-      for (int ct = 0; ct < 3; ++ct) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(wsb + row * WSB_LD + 64 * ct + 8 * cc);
-        if (m < p.M) *reinterpret_cast<bf16x8*>(p.xn_out + m * WN_N + nw + 64 * ct + 8 * cc) = v;
-      }
-    }
-  }
-}
-
-// --------------------------------------------------------------------------------------
 // bf16 kernel "s64": 64x128 tile, 4 waves (2x2, 32x64 each), BK = 64, three 24-KiB stages, for problems
 // that give the 128x128 kernels fewer than one workgroup per CU (the 17-token SPPP configurations,
 // ViT-Tiny, heads): twice the workgroups, a three-deep DMA ring instead of the double buffer, and the
@@ -2543,33 +2326,6 @@ extern "C" int64_t favit_gemm_grouped_tn_workspace(const favit_gemm_t* gs, int32
   long tiles = 0;
   for (int i = 0; i < count; ++i) tiles += ((gs[i].M + P4_BM - 1) / P4_BM) * ((gs[i].N + BN - 1) / BN);
   return (int64_t)(grouped_nsplit(tiles, gs[0].K, nullptr) * grouped_slab_floats(gs, count) * 4);
-}
-
-extern "C" int favit_gemm_residual_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                                      const float* residual, int64_t ld_res, float* x_out, int64_t ldx,
-                                      const float* gamma, const float* beta, void* xn_out, float* mean, float* rstd,
-                                      int64_t M, int32_t N, int64_t K, float eps, void* stream) {
-  if (!A || !W || !residual || !x_out || !gamma || !beta || !xn_out || !mean || !rstd || M <= 0 || K <= 0) return FAVIT_ERR_INVALID;
-  if (N != WN_N || (K % P4_BK) != 0 || M < 256) return FAVIT_ERR_UNSUPPORTED;       // whole rows of 384 columns only
-  if (!aligned(A, 16) || !aligned(W, 16) || !aligned(residual, 16) || !aligned(x_out, 16) || !aligned(xn_out, 16) ||
-      !aligned(gamma, 16) || !aligned(beta, 16) || (bias && !aligned(bias, 16)) || (lda % 8) || (ldw % 8) || (ld_res % 4) ||
-      (ldx % 4))
-    return FAVIT_ERR_ALIGN;
-  WnParams p;
-  p.A = reinterpret_cast<const bf16_t*>(A); p.lda = lda;
-  p.W = reinterpret_cast<const bf16_t*>(W); p.ldw = ldw;
-  p.bias = bias; p.residual = residual; p.ld_res = ld_res; p.x_out = x_out; p.ldx = ldx;
-  p.gamma = gamma; p.beta = beta; p.xn_out = reinterpret_cast<bf16_t*>(xn_out); p.mean = mean; p.rstd = rstd;
-  p.M = M; p.K = K; p.eps = eps;
-#ifdef FAVIT_PROBE
-  p.dbg = getenv("FAVIT_WN_DBG") ? atoi(getenv("FAVIT_WN_DBG")) : 0;
-#else
-  p.dbg = 0;
-#endif
-  favit_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_wn_ln_kernel), WN_LDS);
-  hipLaunchKernelGGL(gemm_bf16_wn_ln_kernel, dim3((unsigned)((M + 255) / 256)), dim3(WN_THREADS), WN_LDS, as_stream(stream), p);
-  FAVIT_CHECK_LAUNCH();
-  return FAVIT_OK;
 }
 
 extern "C" int favit_gemm_grouped_tn_ws(const favit_gemm_t* gs, int32_t count, void* workspace, int64_t workspace_bytes,

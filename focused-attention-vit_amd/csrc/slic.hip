@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void slic_seed_kernel(const short* __restrict__
 // four feature loads are in flight together and up to eight workgroups share a CU.  The first form, one pixel per
 // thread in 1024-thread workgroups (two per CU), spent its time in the serial chain centre load -> barrier -> pixel
 // load -> loop -> reduction -> barrier -> atomics of each workgroup: 163 us per iteration for 57 MB.
-constexpr int ASG_THREADS = 256, ASG_PPT = 4, ASG_ROUNDS = 4, ASG_TILE = ASG_THREADS * ASG_PPT * ASG_ROUNDS;
+constexpr int ASG_THREADS = 256, ASG_PPT = 4, ASG_ROUNDS = 1, ASG_TILE = ASG_THREADS * ASG_PPT * ASG_ROUNDS;
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
 template <bool FAST>
 __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* __restrict__ feat, uint8_t* __restrict__ labels,
@@ -216,9 +216,8 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
   const unsigned coef32 = (unsigned)coef;
   const unsigned win = 4u * (unsigned)step;
   __syncthreads();
-  // ASG_ROUNDS rounds of ASG_PPT pixels per thread: the per-cluster sums of 4096 pixels leave the workgroup as ONE set of
-  // 64-bit global atomics (every workgroup of an image adds to the same K x 6 addresses: with 1024 pixels per
-  // workgroup those contended atomics were a third of the kernel)
+  // (ASG_ROUNDS > 1 -- more pixels per workgroup, fewer of the contended 64-bit global atomics at its end -- measured
+  // slower: 4096 pixels per workgroup leave 1,664 workgroups for 2,048 slots and the k-means pass went 1.56 -> 2.01 ms)
   for (int rnd = 0; rnd < ASG_ROUNDS; ++rnd) {
   short4_t qv[ASG_PPT];
   int pp[ASG_PPT];
@@ -239,16 +238,21 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
       if (FAST) {
         const s16x2_t pyx = {(short)(16 * y), (short)(16 * x)};
         const s16x2_t pla = {(short)q0, (short)q1};
+        // branch-free body (a centre outside the window gets the distance ~0, which never wins the strict <): the
+        // compiler unrolls it and issues the LDS reads of four centres together instead of one dependent
+        // read -> test -> branch chain per centre
+#pragma unroll 4
         for (int k = 0; k < K; ++k) {
           const int c_yx = cpk[k][0], c_la = cpk[k][1], c_b = cpk[k][2], ylo = cpk[k][3], xlo = cpk[k][4];
           // y in [cy - 2 step, cy + 2 step]  <=>  (unsigned)(y - (cy - 2 step)) <= 4 step
-          if ((unsigned)(y - ylo) > win || (unsigned)(x - xlo) > win) continue;
+          const bool inwin = ((unsigned)(y - ylo) <= win) & ((unsigned)(x - xlo) <= win);
           const s16x2_t dyx = pyx - __builtin_bit_cast(s16x2_t, c_yx);
           const s16x2_t dla = pla - __builtin_bit_cast(s16x2_t, c_la);
           const int db = q2 - c_b;
           const unsigned sp = (unsigned)__builtin_amdgcn_sdot2(dyx, dyx, 0, false);
           const unsigned cq = (unsigned)__builtin_amdgcn_sdot2(dla, dla, __mul24(db, db), false);
-          const unsigned long long d = (unsigned long long)coef32 * cq + sp;
+          unsigned long long d = (unsigned long long)coef32 * cq + sp;
+          d = inwin ? d : ~0ull;
           if (d < best) { best = d; best_k = k; }
         }
       } else {

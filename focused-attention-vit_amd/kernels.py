@@ -279,31 +279,6 @@ def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None,
     return (dx, dx_lp, None, None) if acc else (dx, dx_lp, dg, db)
 
 
-def gemm_residual_ln(a, w, bias, residual, gamma, beta, eps=1e-5):
-    """(x_new fp32, LN(x_new) bf16, mean, rstd) with x_new = a @ w.T + bias + residual in ONE launch (whole-row GEMM
-    with the next LayerNorm in its epilogue), or None when the shape is not served (N != 384, K % 32, M < 256,
-    non-bf16 operands): the caller then runs gemm + layernorm_fwd."""
-    require_gpu(a, w, residual, gamma, beta)
-    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or residual.dtype != torch.float32:
-        return None
-    M, Kd = a.shape
-    N = w.shape[0]
-    if N != 384 or Kd % 32 or M < 256 or a.stride(1) != 1 or w.stride(1) != 1 or residual.stride(1) != 1:
-        return None
-    dev = a.device
-    x_out = torch.empty((M, N), dtype=torch.float32, device=dev)
-    xn = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-    mean = torch.empty(M, dtype=torch.float32, device=dev)
-    rstd = torch.empty(M, dtype=torch.float32, device=dev)
-    rc = _abi.lib().favit_gemm_residual_ln(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(residual), residual.stride(0),
-                                           _p(x_out), N, _p(gamma), _p(beta), _p(xn), _p(mean), _p(rstd), M, N, Kd,
-                                           float(eps), _st())
-    if rc in (_abi.ERR_UNSUPPORTED, _abi.ERR_ALIGN):
-        return None
-    _abi.check(rc, "favit_gemm_residual_ln")
-    return x_out, xn, mean, rstd
-
-
 def reduce_rows_multi(entries):
     """entries: [(part [2, rows, cols] fp32 contiguous, out0 [cols], out1 [cols])] -> out0 += colsum(part[0]),
     out1 += colsum(part[1]) for every entry in ONE launch (at most 32 entries per launch)."""

@@ -131,16 +131,6 @@ int64_t favit_gemm_grouped_tn_workspace(const favit_gemm_t* gs, int32_t count);
 int favit_gemm_grouped_tn_ws(const favit_gemm_t* gs, int32_t count, void* workspace, int64_t workspace_bytes,
                              void* stream);
 
-/* y = A . W^T + bias + residual (fp32, the new residual stream) AND its LayerNorm in one launch: the epilogue of the
- * projection / fc2 GEMM of a pre-LN block followed by the next LayerNorm (reference models/vit.py:165-179:
- * x = x + attn(norm1(x)); x = x + mlp(norm2(x))).  A [M, K] and W [N, K] bf16 row-major, residual / x_out fp32 with
- * row strides, xn_out bf16 [M, N] contiguous, mean / rstd fp32 [M] (what favit_layernorm_bwd needs).
- * Whole rows per workgroup: N == 384 only (FAVIT_ERR_UNSUPPORTED otherwise: the caller runs favit_gemm + favit_layernorm_fwd). */
-int favit_gemm_residual_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                           const float* residual, int64_t ld_res, float* x_out, int64_t ldx, const float* gamma,
-                           const float* beta, void* xn_out, float* mean, float* rstd, int64_t M, int32_t N, int64_t K,
-                           float eps, void* stream);
-
 /* ------------------------------------------------------------------------------------
  * FP8 operand preparation (BASELINE.json configs[3] "fp8 MFMA path"; no reference counterpart:
  * the reference is fp32 only).  Per-tensor scaling, computed on the device:

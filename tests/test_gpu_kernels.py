@@ -655,37 +655,6 @@ def test_gemm_ping_pong_kernel(K, bk, M, N, Kd, forced, out_dtype, epi, monkeypa
     assert rel_l2(out.float(), ref) < (1e-2 if out_dtype == torch.bfloat16 else 2e-5)
 
 
-@pytest.mark.parametrize("M,Kd,with_bias", [(50432, 384, True), (50432, 1536, True), (4160 + 77, 96, False), (256, 64, True)])
-def test_gemm_residual_layernorm_whole_row_kernel(K, M, Kd, with_bias):
-    """favit_gemm_residual_ln: x = A.W^T + bias + residual and LN(x) (bf16), mean, rstd from ONE launch (256x384 tile:
-    whole rows per workgroup) against the two-kernel sequence it could replace and against fp64; ragged M, no bias,
-    a single tile.  (The model path does not use it: it measures at parity with GEMM + LayerNorm)"""
-    g = torch.Generator(device=DEV).manual_seed(M + Kd)
-    D = 384
-    a = _rand((M, Kd), torch.bfloat16, g)
-    w = (_rand((D, Kd), torch.float32, g) * Kd ** -0.5).to(torch.bfloat16)
-    bias = _rand((D,), torch.float32, g) if with_bias else None
-    res = _rand((M, D), torch.float32, g) * 3 + 0.5
-    gamma = torch.rand(D, device=DEV, generator=g) + 0.5
-    beta = _rand((D,), torch.float32, g)
-    got = K.gemm_residual_ln(a, w, bias, res, gamma, beta)
-    assert got is not None
-    x, xn, mu, rs = got
-    ref = a.double() @ w.double().t() + res.double() + (bias.double() if with_bias else 0.0)
-    assert rel_l2(x, ref) < 2e-6
-    m64 = ref.mean(1)
-    r64 = (ref.var(1, unbiased=False) + 1e-5).rsqrt()
-    assert rel_l2(mu, m64) < 1e-5 and rel_l2(rs, r64) < 1e-5
-    assert rel_l2(xn.float(), (ref - m64[:, None]) * r64[:, None] * gamma.double() + beta.double()) < 4e-3   # bf16 output
-    out = torch.empty((M, D), dtype=torch.float32, device=DEV)
-    K.gemm(a, w, out, M, D, Kd, Kd, Kd, D, bias=bias, residual=res, ld_res=D)
-    xn2, mu2, rs2 = K.layernorm_fwd(out, D, gamma, beta, M, D, torch.bfloat16)
-    assert rel_l2(x, out) < 1e-6 and rel_l2(mu, mu2) < 1e-5 and rel_l2(rs, rs2) < 1e-5
-    assert (xn.float() - xn2.float()).abs().max() <= 0.0625            # at most a bf16 rounding flip of O(4) values
-    # shapes it does not serve are declined (None), never mis-computed
-    assert K.gemm_residual_ln(a, w[:256], None, res[:, :256].contiguous(), gamma[:256], beta[:256]) is None
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,Kd", [(300, 200, 96), (1000, 256, 128), (21760 + 37, 384, 64), (50432, 1536, 384)])
 def test_gemm_gelu_savegrad_and_mulaux_epilogues(K, dtype, M, N, Kd):
