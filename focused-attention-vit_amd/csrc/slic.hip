@@ -185,23 +185,32 @@ __global__ __launch_bounds__(64) void slic_seed_kernel(const short* __restrict__
 // four feature loads are in flight together and up to eight workgroups share a CU.  The first form, one pixel per
 // thread in 1024-thread workgroups (two per CU), spent its time in the serial chain centre load -> barrier -> pixel
 // load -> loop -> reduction -> barrier -> atomics of each workgroup: 163 us per iteration for 57 MB.
-constexpr int ASG_THREADS = 256, ASG_PPT = 4, ASG_ROUNDS = 1, ASG_TILE = ASG_THREADS * ASG_PPT * ASG_ROUNDS;
+constexpr int ASG_THREADS = 256, ASG_PPT = 4, ASG_TILE = ASG_THREADS * ASG_PPT;
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
 template <bool FAST>
 __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* __restrict__ feat, uint8_t* __restrict__ labels,
-                                                                  void* ws, int K, int H, int W, int step, long long coef) {
+                                                                  void* ws, int K, int H, int W, int step, long long coef
+#ifdef FAVIT_PROBE
+                                                                  , int dbg      // probe build: 1 no candidate loop, 2 no
+#endif                                                                           // reduction, 4 no global atomics (timing)
+) {
+#ifndef FAVIT_PROBE
+  constexpr int dbg = 0;
+#endif
   __shared__ int cen[SLIC_MAXK][5];      // y16, x16, l, a, b
   // FAST form of a centre: packed 16-bit pairs (y16, x16) and (l, a), b, and the window origin (cy - 2 step, cx - 2 step):
   // the differences are two v_pk_sub_i16, the two sums of squares two v_dot2_i32_i16 (every value fits 16 bits and
   // every sum 31 bits for H, W <= 2047 and features within +-8191), the window test two unsigned compares
   __shared__ __attribute__((aligned(16))) int cpk[SLIC_MAXK][8];
-  __shared__ int sums[SLIC_MAXK][6];     // this workgroup's <= 4096 pixels: 16 * 2047 * 4096 fits 32 bits
+  __shared__ int sums[SLIC_MAXK][6];     // this workgroup's <= 1024 pixels: fits 32 bits
+  extern __shared__ int bins[];          // [16 copies][K * 6 + 1]
   const int b = blockIdx.y, tid = threadIdx.x;
   const int HW = H * W;
+  const int bstride = K * 6 + 1;
   const short* f = feat + (long)b * HW * 4;
   uint8_t* lab = labels + (long)b * HW;
   for (int i = tid; i < K * 5; i += ASG_THREADS) cen[i / 5][i % 5] = slic_cen(ws, b, K)[i];
-  for (int i = tid; i < K * 6; i += ASG_THREADS) sums[i / 6][i % 6] = 0;
+  for (int i = tid; i < 16 * bstride; i += ASG_THREADS) bins[i] = 0;
   if (FAST) {
     for (int k = tid; k < K; k += ASG_THREADS) {
       const int* c = slic_cen(ws, b, K) + 5 * k;
@@ -216,26 +225,30 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
   const unsigned coef32 = (unsigned)coef;
   const unsigned win = 4u * (unsigned)step;
   __syncthreads();
-  // (ASG_ROUNDS > 1 -- more pixels per workgroup, fewer of the contended 64-bit global atomics at its end -- measured
-  // slower: 4096 pixels per workgroup leave 1,664 workgroups for 2,048 slots and the k-means pass went 1.56 -> 2.01 ms)
-  for (int rnd = 0; rnd < ASG_ROUNDS; ++rnd) {
+  // A thread owns ASG_PPT CONSECUTIVE pixels (p = base + ASG_PPT * tid + j: a wave still reads 2 KiB contiguously).
+  // Neighbouring pixels mostly share their cluster, so the per-cluster sums are first folded inside the thread
+  // (equal neighbours: entry j into entry j - 1, from the right, so a run ends up in its first pixel) and only then
+  // reduced across the wave, slot by slot: slot 0 has every lane, slots 1..3 only the lanes where a new run starts.
+  // The wave-level reduction was 60 % of the kernel when it ran once per pixel slot (probe switches).
+  // (More pixels per workgroup -- fewer of the contended 64-bit global atomics at its end -- measured slower: 4096 per
+  // workgroup leave 1,664 workgroups for 2,048 slots and the k-means pass went 1.56 -> 2.01 ms.)
   short4_t qv[ASG_PPT];
-  int pp[ASG_PPT];
+  int bk[ASG_PPT], sy[ASG_PPT], sx[ASG_PPT], sl[ASG_PPT], sa[ASG_PPT], sb[ASG_PPT], sc[ASG_PPT];
+  const int p0 = blockIdx.x * ASG_TILE + ASG_PPT * tid;
+#pragma unroll
+  for (int j = 0; j < ASG_PPT; ++j)
+    qv[j] = p0 + j < HW ? *reinterpret_cast<const short4_t*>(f + (long)(p0 + j) * 4) : (short4_t){0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < ASG_PPT; ++j) {
-    pp[j] = blockIdx.x * ASG_TILE + (rnd * ASG_PPT + j) * ASG_THREADS + tid;
-    qv[j] = pp[j] < HW ? *reinterpret_cast<const short4_t*>(f + (long)pp[j] * 4) : (short4_t){0, 0, 0, 0};
-  }
-#pragma unroll
-  for (int j = 0; j < ASG_PPT; ++j) {
-    const int p = pp[j];
+    const int p = p0 + j;
     const bool live = p < HW;
     int best_k = 255, y = 0, x = 0;
     const int q0 = qv[j][0], q1 = qv[j][1], q2 = qv[j][2];
     if (live) {
       y = p / W; x = p - y * W;
       unsigned long long best = ~0ull;
-      if (FAST) {
+      if (dbg & 1) { best_k = (x * 4 / W) + 4 * (y * 4 / H); best = 0; }
+      else if (FAST) {
         const s16x2_t pyx = {(short)(16 * y), (short)(16 * x)};
         const s16x2_t pla = {(short)q0, (short)q1};
         // branch-free body (a centre outside the window gets the distance ~0, which never wins the strict <): the
@@ -271,25 +284,41 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
       if (best_k == 255) best_k = lab[p];                                    // no window covers the pixel: keep
       else lab[p] = (uint8_t)best_k;
     }
-    // per-cluster sums: reduce over the lanes of the wave that share a cluster, one LDS atomic set per cluster
-    unsigned long long todo = __ballot(live);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int kk = __shfl(best_k, leader, 64);
-      const bool in = live && best_k == kk;
-      const unsigned long long grp = __ballot(in);
-      const int s0 = masked_wave_sum(16 * y, in), s1 = masked_wave_sum(16 * x, in);
-      const int s2 = masked_wave_sum(q0, in), s3 = masked_wave_sum(q1, in), s4 = masked_wave_sum(q2, in);
-      const int cnt = __popcll(grp);
-      if ((tid & 63) == leader && kk < SLIC_MAXK) {
-        atomicAdd(&sums[kk][0], s0); atomicAdd(&sums[kk][1], s1); atomicAdd(&sums[kk][2], s2);
-        atomicAdd(&sums[kk][3], s3); atomicAdd(&sums[kk][4], s4); atomicAdd(&sums[kk][5], cnt);
-      }
-      todo &= ~grp;
+    bk[j] = live ? best_k : -1;                   // -1: no pixel (never equal to a cluster, never reduced)
+    sy[j] = 16 * y; sx[j] = 16 * x; sl[j] = q0; sa[j] = q1; sb[j] = q2; sc[j] = live ? 1 : 0;
+  }
+  // fold equal neighbours inside the thread, from the right
+#pragma unroll
+  for (int j = ASG_PPT - 1; j > 0; --j) {
+    if (bk[j] >= 0 && bk[j] == bk[j - 1]) {
+      sy[j - 1] += sy[j]; sx[j - 1] += sx[j]; sl[j - 1] += sl[j]; sa[j - 1] += sa[j]; sb[j - 1] += sb[j]; sc[j - 1] += sc[j];
+      bk[j] = -1;
     }
   }
-  }   // rounds
+  // per-cluster sums: privatised LDS bins, copy = lane % 16 (rows padded to an odd number of words: the 16 copies of
+  // one (cluster, component) fall into 16 different banks; the four lanes that share a copy are the only same-address
+  // collisions of an instruction).  Six ds_add_u32 per run instead of six wave-wide reductions per (wave, cluster)
+  // group -- those reductions, ~80 VALU instructions per group, were 60 % of the kernel (probe switches).
+  if (!(dbg & 2)) {
+    int* mine = bins + (tid & 15) * bstride;
+#pragma unroll
+    for (int j = 0; j < ASG_PPT; ++j) {
+      if (bk[j] >= 0 && bk[j] < K) {
+        int* d = mine + bk[j] * 6;
+        atomicAdd(d + 0, sy[j]); atomicAdd(d + 1, sx[j]); atomicAdd(d + 2, sl[j]);
+        atomicAdd(d + 3, sa[j]); atomicAdd(d + 4, sb[j]); atomicAdd(d + 5, sc[j]);
+      }
+    }
+  }
   __syncthreads();
+  for (int i = tid; i < K * 6; i += ASG_THREADS) {
+    int t = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t += bins[c * bstride + i];
+    sums[i / 6][i % 6] = t;
+  }
+  __syncthreads();
+  if (dbg & 4) return;
   for (int i = tid; i < K * 6; i += ASG_THREADS)
     if (sums[i / 6][i % 6] != 0)
       atomicAdd(reinterpret_cast<unsigned long long*>(slic_sums(ws, b, K)) + i, (unsigned long long)(long long)sums[i / 6][i % 6]);
@@ -542,13 +571,19 @@ extern "C" int favit_slic_cluster(const int16_t* feat, uint8_t* labels, const in
   hipLaunchKernelGGL(slic_seed_kernel, dim3((unsigned)B), dim3(64), 0, st, reinterpret_cast<const short*>(feat), init_yx, ws, K, H, W);
   FAVIT_CHECK_LAUNCH();
   const dim3 grid((unsigned)((HW + ASG_TILE - 1) / ASG_TILE), (unsigned)B);
+#ifdef FAVIT_PROBE
+  const int dbg = getenv("FAVIT_SLIC_DBG") ? atoi(getenv("FAVIT_SLIC_DBG")) : 0;
+#define FAVIT_SLIC_DBG_ARG , dbg
+#else
+#define FAVIT_SLIC_DBG_ARG
+#endif
   for (int it = 0; it < iters; ++it) {
     if (H <= 2047 && W <= 2047 && coef < (1LL << 32))
-      hipLaunchKernelGGL(slic_assign_kernel<true>, grid, dim3(ASG_THREADS), 0, st, reinterpret_cast<const short*>(feat), labels,
-                         ws, K, H, W, step, (long long)coef);
+      hipLaunchKernelGGL(slic_assign_kernel<true>, grid, dim3(ASG_THREADS), (size_t)16 * (K * 6 + 1) * 4, st, reinterpret_cast<const short*>(feat), labels,
+                         ws, K, H, W, step, (long long)coef FAVIT_SLIC_DBG_ARG);
     else
-      hipLaunchKernelGGL(slic_assign_kernel<false>, grid, dim3(ASG_THREADS), 0, st, reinterpret_cast<const short*>(feat), labels,
-                         ws, K, H, W, step, (long long)coef);
+      hipLaunchKernelGGL(slic_assign_kernel<false>, grid, dim3(ASG_THREADS), (size_t)16 * (K * 6 + 1) * 4, st, reinterpret_cast<const short*>(feat), labels,
+                         ws, K, H, W, step, (long long)coef FAVIT_SLIC_DBG_ARG);
     FAVIT_CHECK_LAUNCH();
     hipLaunchKernelGGL(slic_update_kernel, dim3((unsigned)B), dim3(64), 0, st, ws, K);
     FAVIT_CHECK_LAUNCH();

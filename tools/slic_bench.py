@@ -5,6 +5,8 @@ import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 pkg = importlib.import_module("focused-attention-vit_amd")
+if os.environ.get("FAVIT_SLIC_DBG"):      # probe build: work-skipping switches of the assignment kernel (timing only)
+    pkg._abi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_build", "libfavit_probe.so")
 K, A = pkg.kernels, pkg._abi
 dev = "cuda"
 B, H, W, nseg = int(os.environ.get("B", "128")), 224, 224, 16
