@@ -24,6 +24,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 // name of the kernel family the last favit_gemm / grouped launch of this host thread dispatched to
@@ -1978,6 +1979,7 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   if (atomic && g->out_dtype != FAVIT_F32) return FAVIT_ERR_UNSUPPORTED;
 
   KParams kp;
+  memset(&kp, 0, sizeof(kp));
   kp.A = g->A; kp.B = g->B; kp.C = g->C;
   kp.bias = g->bias; kp.aux_in = g->aux_in; kp.aux_out = g->aux_out; kp.residual = g->residual;
   kp.a_rowsum = g->a_rowsum;
@@ -2213,6 +2215,7 @@ int grouped_tn_impl(const favit_gemm_t* gs, int32_t count, float* ws, int64_t ws
   if (!gs || count <= 0 || count > GROUP_MAX) return FAVIT_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   GroupParams gp;
+  memset(&gp, 0, sizeof(gp));          // every field of every KParams defined, whatever is added to the struct later
   gp.count = count;
   gp.pad_ = 0;
   const long K = gs[0].K;
