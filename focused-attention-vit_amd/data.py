@@ -97,7 +97,24 @@ class DeviceTransform:
             rh, rw = _resized_size(H, W, int(S * 1.14))
             p[:, 2], p[:, 3], p[:, 5], p[:, 6] = H, W, rh, rw
             p[:, 7], p[:, 8] = int(round((rh - S) / 2.0)), int(round((rw - S) / 2.0))
+        self.check_params(p)
         return p
+
+    MAX_TAPS = 64          # csrc/image.hip: filter taps per output position the resampling kernels hold
+
+    @classmethod
+    def check_params(cls, p: np.ndarray) -> None:
+        """Pillow's triangle filter spans 2 * max(1, crop / resized) source pixels: beyond MAX_TAPS the kernels would
+        truncate the window and silently stop being bit-identical to Pillow, so such a row is refused here (a crop box
+        downscaled more than ~31x: a very large source image or crop)."""
+        for ax, (c, r) in enumerate(((p[:, 2], p[:, 5]), (p[:, 3], p[:, 6]))):
+            scale = np.maximum(1.0, c.astype(np.float64) / np.maximum(r, 1))
+            taps = np.ceil(2.0 * scale).astype(np.int64) + 2
+            if (taps > cls.MAX_TAPS).any():
+                b = int(np.argmax(taps))
+                raise ValueError(f"DeviceTransform: image {b} is downscaled {scale[b]:.1f}x along axis {ax} "
+                                 f"({int(c[b])} -> {int(r[b])} pixels): {int(taps[b])} filter taps exceed the kernels' "
+                                 f"{cls.MAX_TAPS}; resize such sources on the host first")
 
     def __call__(self, batch_u8: torch.Tensor, params: Optional[np.ndarray] = None, want_bytes: bool = False):
         """batch_u8: uint8 [B, H, W, C] on the GPU -> fp32 [B, C, S, S] (and the resized bytes if want_bytes)."""
@@ -108,6 +125,8 @@ class DeviceTransform:
         B, H, W, Cc = batch_u8.shape
         if params is None:
             params = self.params(B, H, W)
+        else:
+            self.check_params(np.asarray(params))
         prm = torch.from_numpy(np.ascontiguousarray(params, dtype=np.int32)).to(batch_u8.device, non_blocking=True)
         ch_max = int(params[:, 2].max())
         S = self.S
@@ -151,7 +170,11 @@ class DeviceLoader:
         imgs = torch.as_tensor(np.asarray(imgs)) if not torch.is_tensor(imgs) else imgs
         labels = torch.as_tensor(np.asarray(labels), dtype=torch.int64) if not torch.is_tensor(labels) else labels.to(torch.int64)
         if imgs.is_pinned() and labels.is_pinned():
-            src = (imgs, labels)                          # the producer already wrote into page-locked memory: no staging copy
+            # The producer already wrote into page-locked memory: no staging copy.  CONTRACT: the asynchronous
+            # host-to-device copy reads that memory until the batch has been yielded, so the producer must not
+            # rewrite a pinned buffer before the loader has yielded the batch made from it (hand out a fresh or a
+            # rotated buffer per batch; bench.py --host-input rotates four).
+            src = (imgs, labels)
         else:
             buf = self._pin[slot]
             if buf is None or buf[0].shape != imgs.shape or buf[1].shape != labels.shape:

@@ -131,3 +131,19 @@ def test_harness_epoch_loop_and_measurements(favit, tmp_path):
     lines = path.read_text().strip().splitlines()
     assert lines[0].split(",") == list(row.keys()) and len(lines) == 2
     favit.functional.clear_lp_mirrors()
+
+
+def test_transform_refuses_downscales_beyond_the_kernels_tap_window(favit):
+    """More than 64 filter taps per output pixel (a crop downscaled > ~31x) used to be truncated silently; the
+    host-side parameter check refuses it (no GPU needed: the check runs before any launch)."""
+    T = favit.data.DeviceTransform
+    ok = np.zeros((2, 12), dtype=np.int32)
+    ok[:, 2], ok[:, 3], ok[:, 5], ok[:, 6] = 500, 375, 224, 224
+    T.check_params(ok)
+    bad = ok.copy()
+    bad[1, 2], bad[1, 5] = 8000, 224                       # 35.7x along the vertical axis -> 74 taps
+    with pytest.raises(ValueError, match="filter taps"):
+        T.check_params(bad)
+    tf = T("resize", 32, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+    with pytest.raises(ValueError, match="filter taps"):
+        tf.params(1, 2048, 2048)                           # 64x downscale

@@ -8,8 +8,8 @@ set -o pipefail
 tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
-prof=$root/profiles
-mkdir -p $out
+prof=$out/final   # (only gpurun_out/ travels back from the GPU box: copy prof_$tag/final/* into profiles/ afterwards)
+mkdir -p $out $out/final
 cd /tmp && export TMPDIR=/tmp
 run_stats() {   # name, bench args...
   local name=$1; shift
