@@ -35,7 +35,6 @@ class GemmDesc(C.Structure):
         ("in_dtype", i32), ("out_dtype", i32), ("act", i32), ("accumulate", i32), ("split_k", i32),
         ("alpha", f32), ("dropout_p", f32), ("fp8_fmt", i32), ("dropout_seed", u64),
         ("scale_a", vp), ("scale_b", vp),
-        ("q_out", vp), ("q_amax", vp), ("q_amax_next", vp), ("q_amax_clear", vp), ("q_scale_inv", vp), ("q_fmt", i32),
     ]
 
 

@@ -77,13 +77,6 @@ struct KParams {
 #endif
   const float* scale_a;   // fp8 operands: device dequantisation factors (or null)
   const float* scale_b;
-  // fused fp8 copy of a bf16 output (favit_gemm_t::q_out): delayed per-tensor scaling as favit_fp8_quantize does it
-  uint8_t* q_out;         // [M, N] fp8 bytes (or null)
-  const float* q_amax;    // FAVIT_FP8_AMAX_SLOTS partial maxima the scale comes from (the previous call's tensor)
-  float* q_amax_next;     // slots this tensor's maxima go to
-  float* q_amax_clear;    // slots zeroed for the call after next
-  float* q_scale_inv;     // [1] dequantisation factor written for the consumer GEMM
-  int q_fmt;              // FAVIT_E4M3 | FAVIT_E5M2
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -717,10 +710,9 @@ constexpr int WEPI_LD = 68;                         // padded fp32 row
 constexpr int WEPI_BYTES = 32 * WEPI_LD * 4;        // 8704 B per wave
 
 // rows [16*Q, 16*(Q+NI)) of the wave's 64x64 accumulator tile (NI = 1 or 2 groups of 16 rows)
-template <typename InT, typename OutT, int Q, int NI, int NJ = 4, int CB = 0, bool QF = false>
+template <typename InT, typename OutT, int Q, int NI, int NJ = 4, int CB = 0>
 __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4 (&acc)[4][NJ], OutT* C, long mbase,
-                                              long nbase, int lane, float* wl, bool first_split, float alpha,
-                                              float qscale = 0.f, float* qmax = nullptr) {
+                                              long nbase, int lane, float* wl, bool first_split, float alpha) {
   const bool fast = p.c_vec && (nbase + 64 <= p.N);
   {
 #pragma unroll
@@ -845,35 +837,6 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
           }
         }
         store_vec(C + m * p.ldc + n, a);
-        if constexpr (QF && sizeof(OutT) == 2) {
-          if (qmax) {
-            // fp8 copy of the row segment: the bf16-ROUNDED values x scale, clamped, round-to-nearest-even -- the bytes
-            // favit_fp8_quantize would produce from the stored tensor -- and this tensor's amax for the site's next call
-            const float fmax = p.q_fmt == FAVIT_E4M3 ? 448.0f : 57344.0f;
-            float f[8];
-            float mx = *qmax;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-              const float r = (float)(bf16_t)a[c];
-              mx = fmaxf(mx, fabsf(r));
-              f[c] = fminf(fmaxf(r * qscale, -fmax), fmax);
-            }
-            *qmax = mx;
-            unsigned w0, w1;
-            if (p.q_fmt == FAVIT_E4M3) {
-              w0 = ((unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false) & 0xffffu) |
-                   ((unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], 0, false) << 16);
-              w1 = ((unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false) & 0xffffu) |
-                   ((unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], 0, false) << 16);
-            } else {
-              w0 = ((unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], 0, false) & 0xffffu) |
-                   ((unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], 0, false) << 16);
-              w1 = ((unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], 0, false) & 0xffffu) |
-                   ((unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], 0, false) << 16);
-            }
-            *reinterpret_cast<uint2*>(p.q_out + m * p.N + n) = make_uint2(w0, w1);
-          }
-        }
       }
     } else {
 #pragma unroll
@@ -904,34 +867,9 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
   }
 }
 
-// QF: the fused fp8 copy of the output exists in this instantiation (the fp8 kernels with a bf16 output only: the
-// bf16 kernels of the headline path must not carry its registers -- with it they went from 102-112 VGPRs to 128 + spills)
-template <typename InT, typename OutT, bool QF = false>
+template <typename InT, typename OutT>
 __device__ __forceinline__ void wave_epilogue(const KParams& p, const f32x4 (&acc)[4][4], OutT* C, long mbase,
                                               long nbase, int lane, float* wl, bool first_split, float alpha) {
-  if constexpr (QF && sizeof(OutT) == 2) {
-    if (p.q_out) {
-      // delayed scaling: the scale is the maximum of the slots the site's previous call filled (final at its end)
-      float am = 0.f;
-      for (int i = lane; i < FAVIT_FP8_AMAX_SLOTS; i += 64) am = fmaxf(am, p.q_amax[i]);
-      am = wave_max(am);
-      const float fmax = p.q_fmt == FAVIT_E4M3 ? 448.0f : 57344.0f;
-      const float qscale = am > 0.f ? __fdiv_rn(fmax, am) : 1.0f;
-      const bool first = blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x >> 6) == 0;
-      if (first) {
-        if (lane == 0) p.q_scale_inv[0] = am > 0.f ? __fdiv_rn(am, fmax) : 1.0f;
-        for (int i = lane; i < FAVIT_FP8_AMAX_SLOTS; i += 64) p.q_amax_clear[i] = 0.f;
-      }
-      float qmax = 0.f;
-      wave_epilogue_rows<InT, OutT, 0, 2, 4, 0, true>(p, acc, C, mbase, nbase, lane, wl, first_split, alpha, qscale, &qmax);
-      wave_epilogue_rows<InT, OutT, 2, 2, 4, 0, true>(p, acc, C, mbase, nbase, lane, wl, first_split, alpha, qscale, &qmax);
-      qmax = wave_max(qmax);
-      if (lane == 0 && qmax > 0.f)
-        atomicMax(reinterpret_cast<unsigned int*>(p.q_amax_next) + ((blockIdx.x * 8 + (threadIdx.x >> 6)) & (FAVIT_FP8_AMAX_SLOTS - 1)),
-                  __float_as_uint(qmax));
-      return;
-    }
-  }
   wave_epilogue_rows<InT, OutT, 0, 2>(p, acc, C, mbase, nbase, lane, wl, first_split, alpha);
   wave_epilogue_rows<InT, OutT, 2, 2>(p, acc, C, mbase, nbase, lane, wl, first_split, alpha);
 }
@@ -958,7 +896,7 @@ __device__ __forceinline__ f32x4 mfma_tile(const bf16x8& bfrag, const bf16x8& af
   }
 }
 
-template <bool AK, bool BKM, typename OutT, int F8 = 0, bool QF = false>
+template <bool AK, bool BKM, typename OutT, int F8 = 0>
 __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, int z) {
   static_assert(F8 == 0 || (AK && BKM), "fp8 operands are k-major");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1128,8 +1066,8 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
 #ifdef FAVIT_PROBE
   if (tl) tl1 = __builtin_amdgcn_s_memrealtime();
 #endif
-  wave_epilogue<bf16_t, OutT, QF>(p, acc, C, m0 + wr * 64, n0 + wc * 64, lane,
-                                  reinterpret_cast<float*>(smem + wave * WEPI_BYTES), split == 0, alpha);
+  wave_epilogue<bf16_t, OutT>(p, acc, C, m0 + wr * 64, n0 + wc * 64, lane,
+                              reinterpret_cast<float*>(smem + wave * WEPI_BYTES), split == 0, alpha);
 #ifdef FAVIT_PROBE
   if (p.dbg & 128) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
@@ -1225,11 +1163,11 @@ __global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_kernel(KParams p) 
 }
 
 // fp8 operands (F8 = 1: e4m3 x e4m3, 2: e5m2 A x e4m3 B), NT layout only
-template <typename OutT, int F8, bool QF = false>
+template <typename OutT, int F8>
 __global__ __launch_bounds__(P4_THREADS, 4) void gemm_fp8_p4_kernel(KParams p) {
   int tile, split;
   tile_and_split(p, tile, split);
-  p4_body<true, true, OutT, F8, QF>(p, tile, split, blockIdx.z);
+  p4_body<true, true, OutT, F8>(p, tile, split, blockIdx.z);
 }
 
 // --------------------------------------------------------------------------------------
@@ -2061,16 +1999,6 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
   kp.alpha = g->alpha;
   kp.scale_a = fp8 ? g->scale_a : nullptr;
   kp.scale_b = fp8 ? g->scale_b : nullptr;
-  if (g->q_out) {
-    // fused fp8 copy: only the 256x128 fp8 kernel's vector epilogue writes it (whole 64-column segments per wave)
-    if (!fp8 || g->out_dtype != FAVIT_BF16 || (g->N % 64) != 0 || !g->q_amax || !g->q_amax_next || !g->q_amax_clear ||
-        !g->q_scale_inv || (g->q_fmt != FAVIT_E4M3 && g->q_fmt != FAVIT_E5M2) || g->ldc != g->N ||
-        !aligned(g->q_out, 8))
-      return FAVIT_ERR_UNSUPPORTED;
-    kp.q_out = reinterpret_cast<uint8_t*>(g->q_out);
-    kp.q_amax = g->q_amax; kp.q_amax_next = g->q_amax_next; kp.q_amax_clear = g->q_amax_clear;
-    kp.q_scale_inv = g->q_scale_inv; kp.q_fmt = g->q_fmt;
-  }
 #ifdef FAVIT_PROBE
   kp.dbg = knobs().dbg;
   kp.probe = g_probe_buffer;
@@ -2120,10 +2048,6 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
     if ((kps % 64) != 0) return FAVIT_ERR_UNSUPPORTED;
     const bool a_bf8 = (g->fp8_fmt & 1) != 0;
     if (g->out_dtype == FAVIT_BF16) {
-      if (kp.q_out) {      // the instantiation that also writes the fp8 copy of its output
-        if (a_bf8) return launch_p4(gemm_fp8_p4_kernel<bf16_t, 2, true>, kp, grid8, st);
-        return launch_p4(gemm_fp8_p4_kernel<bf16_t, 1, true>, kp, grid8, st);
-      }
       if (a_bf8) return launch_p4(gemm_fp8_p4_kernel<bf16_t, 2>, kp, grid8, st);
       return launch_p4(gemm_fp8_p4_kernel<bf16_t, 1>, kp, grid8, st);
     }

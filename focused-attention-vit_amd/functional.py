@@ -374,36 +374,15 @@ def _use_fp8(allow, *mats, k_dims=()):
         all(k % 64 == 0 for k in k_dims)
 
 
-def _q_next(spec, N, out_dtype):
-    """spec = (consumer site, role, fmt) of the fp8 GEMM that reads this GEMM's output next.  When that site has a
-    scale history (every call but its first) the producing epilogue writes the fp8 copy itself: returns the argument
-    for kernels.gemm, else None (the consumer quantises in its own pass as before)."""
-    if spec is None or out_dtype != torch.bfloat16 or N % 64:
-        return None
-    hist = _fp8_hist(spec[0], spec[1])
-    if hist is None or hist.calls == 0:
-        return None
-    return (hist, spec[2])
-
-
-def _attach_q8(t, fmt, q_ret):
-    """Hand the fused fp8 copy to the consumer through the same per-tensor cache _q8 uses."""
-    if q_ret is not None:
-        t._favit_q8 = ((fmt, t._version), (q_ret[0], None, q_ret[1]))
-
-
 def lin_fwd(a, w_c, bias, M, N, Kd, out_dtype, *, act=ACT_NONE, residual=None, want_pre=False, drop=(0.0, 0),
-            allow_fp8=True, site=None, q_next=None):
+            allow_fp8=True, site=None):
     out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     pre = torch.empty((M, N), dtype=out_dtype, device=a.device) if want_pre else None
     if _use_fp8(allow_fp8, a, w_c, k_dims=(Kd,)):
         aq, _, sa = _q8(a, E4M3, hist=_fp8_hist(site, "a"))
         wq, _, sw = _q8(w_c, E4M3, want_t=True, hist=_fp8_hist(site, "w"))      # the backward wants W^T from the same pass
-        qn = _q_next(q_next, N, out_dtype)
-        qr = K.gemm(aq, wq, out, M, N, Kd, Kd, Kd, N, bias=bias, act=act, aux_out=pre, ld_aux_out=N, residual=residual,
-                    ld_res=N, dropout_p=drop[0], dropout_seed=drop[1], scale_a=sa, scale_b=sw, q_next=qn)
-        if qn is not None:
-            _attach_q8(out, q_next[2], qr)
+        K.gemm(aq, wq, out, M, N, Kd, Kd, Kd, N, bias=bias, act=act, aux_out=pre, ld_aux_out=N, residual=residual,
+               ld_res=N, dropout_p=drop[0], dropout_seed=drop[1], scale_a=sa, scale_b=sw)
         return (out, pre) if want_pre else out
     K.gemm(a, w_c, out, M, N, Kd, Kd, Kd, N, bias=bias, act=act, aux_out=pre, ld_aux_out=N, residual=residual,
            ld_res=N, dropout_p=drop[0], dropout_seed=drop[1])
@@ -411,7 +390,7 @@ def lin_fwd(a, w_c, bias, M, N, Kd, out_dtype, *, act=ACT_NONE, residual=None, w
 
 
 def lin_bwd_x(dy, w_c, M, N, Kd, out_dtype, *, dgelu_pre=None, pre_is_grad=False, drop=(0.0, 0), allow_fp8=True,
-              site=None, q_next=None):
+              site=None):
     """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(pre) * dropout-mask; pre_is_grad: `dgelu_pre` already holds
     gelu'(pre), saved by the forward's ACT_GELU_SAVEGRAD epilogue)."""
     dx = torch.empty((M, Kd), dtype=out_dtype, device=dy.device)
@@ -419,11 +398,8 @@ def lin_bwd_x(dy, w_c, M, N, Kd, out_dtype, *, dgelu_pre=None, pre_is_grad=False
     if _use_fp8(allow_fp8, dy, w_c, k_dims=(N,)) and (dgelu_pre is None or dgelu_pre.dtype == torch.bfloat16):
         dyq, _, sdy = _q8(dy, E5M2, hist=_fp8_hist(site, "dy"))
         _, wqt, sw = _q8(w_c, E4M3, want_t=True, hist=_fp8_hist(site, "w"))      # (cached from the forward)
-        qn = _q_next(q_next, Kd, out_dtype)
-        qr = K.gemm(dyq, wqt, dx, M, Kd, N, N, wqt.stride(0), Kd, act=act, aux_in=dgelu_pre, ld_aux_in=Kd,
-                    dropout_p=drop[0], dropout_seed=drop[1], scale_a=sdy, scale_b=sw, q_next=qn)
-        if qn is not None:
-            _attach_q8(dx, q_next[2], qr)
+        K.gemm(dyq, wqt, dx, M, Kd, N, N, wqt.stride(0), Kd, act=act, aux_in=dgelu_pre, ld_aux_in=Kd,
+               dropout_p=drop[0], dropout_seed=drop[1], scale_a=sdy, scale_b=sw)
         return dx
     K.gemm(dy, w_c, dx, M, Kd, N, N, Kd, Kd, b_kmajor=False, act=act,
            aux_in=dgelu_pre, ld_aux_in=Kd, dropout_p=drop[0], dropout_seed=drop[1])
@@ -799,10 +775,8 @@ class MLPChain:
         # backward epilogue is a multiply: the GELU arithmetic (~20 VALU slots per element) runs once instead of twice
         # (measured: -0.09 ms per cfg2 step; both epilogues stay bound by their 310 MB of HBM traffic).  The fp32 parity mode keeps the pre-activation and the exact erf.
         sg = xn.dtype != torch.float32
-        # fp8 mode: the fc1 epilogue also writes the e4m3 copy of h that fc2 consumes (no quantising pass over the
-        # 4D-wide tensor), from the second call of the site on (delayed scaling needs one measured amax)
         h, pre = lin_fwd(xn, w1_c, b1.detach(), M, Hd, D, xn.dtype, act=ACT_GELU_SAVEGRAD if sg else ACT_GELU,
-                         want_pre=True, drop=(p, s1), site=w1, q_next=(w2, "a", E4M3))
+                         want_pre=True, drop=(p, s1), site=w1)
         y = lin_fwd(h, w2_c, b2.detach(), M, Do, Hd, torch.float32, residual=residual, drop=(p, s2), site=w2)
         return y, (xn, (pre, sg), h, w1_c, w2_c, p, s1, s2, prm)
 
@@ -816,8 +790,7 @@ class MLPChain:
         M, D = xn.shape
         Hd, Do = w1_c.shape[0], w2_c.shape[0]
         dym = K.dropout(dy_lp, p, s2) if (p > 0 and not premasked) else dy_lp
-        dpre = lin_bwd_x(dym, w2_c, M, Do, Hd, xn.dtype, dgelu_pre=pre, pre_is_grad=sg, drop=(p, s1), site=w2,
-                         q_next=(w1, "dy", E5M2))       # the e5m2 copy the fc1 input-gradient GEMM consumes
+        dpre = lin_bwd_x(dym, w2_c, M, Do, Hd, xn.dtype, dgelu_pre=pre, pre_is_grad=sg, drop=(p, s1), site=w2)
         dw2, db2 = lin_bwd_w(dym, h, M, Do, Hd, wp=w2, bp=b2)
         dxn = lin_bwd_x(dpre, w1_c, M, Hd, D, xn.dtype, site=w1)
         dw1, db1 = lin_bwd_w(dpre, xn, M, Hd, D, wp=w1, bp=b1)

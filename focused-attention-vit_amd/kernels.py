@@ -63,11 +63,10 @@ def _st():
 def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias=None, act=ACT_NONE,
          aux_in=None, ld_aux_in=0, aux_out=None, ld_aux_out=0, residual=None, ld_res=0, a_rowsum=None,
          accumulate=False, alpha=1.0, batch=1, batch_inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0), split_k=0,
-         a_off=0, b_off=0, c_off=0, dropout_p=0.0, dropout_seed=0, scale_a=None, scale_b=None, q_next=None):
+         a_off=0, b_off=0, c_off=0, dropout_p=0.0, dropout_seed=0, scale_a=None, scale_b=None):
     """C[m,n] = epilogue(alpha * sum_k A[m,k] B[n,k]).  Offsets/strides are in elements.
     float8 operands (A e4m3 / e5m2, B e4m3; both k-major): scale_a / scale_b are the device scalars
-    written by fp8_quantize.  q_next = (Fp8History of the site that consumes C, fmt): the epilogue also writes the
-    fp8 copy of C with that site's delayed scale (favit_gemm_t::q_out); returns (q, scale_inv) then."""
+    written by fp8_quantize."""
     require_gpu(A, B, Cc)
     fp8 = A.dtype in _FP8_DT
     if fp8:
@@ -98,21 +97,6 @@ def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias
         d.fp8_fmt = 1 if A.dtype == torch.float8_e5m2 else 0
         d.scale_a = scale_a.data_ptr() if scale_a is not None else None
         d.scale_b = scale_b.data_ptr() if scale_b is not None else None
-    q_ret = None
-    if q_next is not None:
-        hist, qfmt = q_next
-        if not fp8 or Cc.dtype != torch.bfloat16 or N % 64 or ldc != N or batch != 1 or hist.calls == 0:
-            raise ValueError("gemm(q_next=...): fp8 operands, a contiguous bf16 output with N % 64 == 0 and a site "
-                             "history that has measured at least one tensor are required")
-        q = torch.empty((M, N), dtype=qfmt, device=Cc.device)
-        sinv = torch.empty(1, dtype=torch.float32, device=Cc.device)
-        base, stride = hist.slots.data_ptr(), 4 * hist.NSLOT
-        cur, nxt, clr = hist.calls % 3, (hist.calls + 1) % 3, (hist.calls + 2) % 3
-        hist.calls += 1
-        d.q_out, d.q_scale_inv = q.data_ptr(), sinv.data_ptr()
-        d.q_amax, d.q_amax_next, d.q_amax_clear = base + stride * cur, base + stride * nxt, base + stride * clr
-        d.q_fmt = _abi.E5M2 if qfmt == torch.float8_e5m2 else _abi.E4M3
-        q_ret = (q, sinv)
     d.act = act
     d.accumulate = int(accumulate)
     d.split_k = split_k
@@ -125,7 +109,7 @@ def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias
         raise TypeError("residual must be fp32")
     if GEMM_TRACE is None:
         _abi.check(_abi.lib().favit_gemm(C.byref(d), _st()), "favit_gemm")
-        return q_ret
+        return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _abi.check(_abi.lib().favit_gemm(C.byref(d), _st()), "favit_gemm")
@@ -133,7 +117,6 @@ def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias
     key = ("fp8" if fp8 else "bf16" if A.dtype == torch.bfloat16 else "f32") + ("_K" if a_kmajor else "_M") + ("K" if b_kmajor else "M") + \
           ("_obf16" if Cc.dtype == torch.bfloat16 else "_of32")
     GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, key, (M, N, K, batch), _abi.lib().favit_gemm_last_kernel().decode()))
-    return q_ret
 
 
 _GROUPED_WS = {}          # device index -> workspace tensor of the slab-mode split-K reduction

@@ -110,16 +110,6 @@ typedef struct favit_gemm_t {
   uint64_t dropout_seed;
   const float* scale_a;   /* FAVIT_FP8 only: device scalars (dequantisation factors) or NULL */
   const float* scale_b;
-  /* Fused fp8 copy of the output (FAVIT_FP8 operands, bf16 output, N % 64 == 0, ldc == N; NULL = none): the epilogue also
-   * writes q_out[m*N + n] = fp8(bf16(C[m,n]) * scale) exactly as favit_fp8_quantize would from the stored tensor, with
-   * DELAYED scaling: scale = fmt_max / max(q_amax[0..FAVIT_FP8_AMAX_SLOTS)), q_scale_inv[0] = 1/scale, this tensor's
-   * maxima go to q_amax_next[], q_amax_clear[] is zeroed -- so the consumer GEMM needs no quantising pass over C. */
-  void* q_out;
-  const float* q_amax;
-  float* q_amax_next;
-  float* q_amax_clear;
-  float* q_scale_inv;
-  int32_t q_fmt;          /* FAVIT_E4M3 | FAVIT_E5M2 */
 } favit_gemm_t;
 
 int favit_gemm(const favit_gemm_t* g, void* stream);

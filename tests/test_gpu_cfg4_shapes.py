@@ -298,49 +298,3 @@ def test_dynamic_lds_limit_grows_with_later_larger_requests():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "_lds_growth_probe.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "LDS_GROWTH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-
-
-@pytest.mark.parametrize("qfmt,epi,M,N,Kd", [(torch.float8_e4m3fn, "gelu_savegrad", T_CFG4, 3072, 768),
-                                             (torch.float8_e5m2, "mulaux", T_CFG4, 3072, 768),
-                                             (torch.float8_e4m3fn, "gelu_savegrad", 1000 + 24, 1536, 384)])
-def test_fp8_gemm_fused_output_copy_equals_the_quantise_pass(K, favit, qfmt, epi, M, N, Kd):
-    """The fp8 GEMM epilogue that also writes the fp8 copy of its bf16 output (favit_gemm_t::q_out; fc1 -> h for fc2,
-    fc2's input gradient -> dpre for fc1's) against the stand-alone pass it replaces, under DELAYED scaling: same
-    history, same bytes, same scale_inv, same amax handed to the next call -- for two consecutive calls."""
-    abi = favit._abi
-    gen = torch.Generator(device=DEV).manual_seed(M + N)
-    afmt = torch.float8_e5m2 if epi == "mulaux" else torch.float8_e4m3fn
-    b = _rand((N, Kd), torch.bfloat16, gen, 0.05)
-    bq, _, sb = K.fp8_quantize(b, torch.float8_e4m3fn)
-    bias = _rand((N,), torch.float32, gen)
-    hist_f, hist_s = K.Fp8History(torch.device(DEV)), K.Fp8History(torch.device(DEV))
-    warm = _rand((64, N), torch.bfloat16, gen, 3.0)                    # the site's first call measures its own tensor
-    K.fp8_quantize(warm, qfmt, hist=hist_f)
-    K.fp8_quantize(warm, qfmt, hist=hist_s)
-    for call, scale in enumerate((1.0, 0.3)):                         # two producing calls: the slots rotate
-        a = _rand((M, Kd), torch.bfloat16, gen, scale)
-        aq, _, sa = K.fp8_quantize(a, afmt)
-        out_f = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
-        out_s = torch.empty_like(out_f)
-        kw = dict(scale_a=sa, scale_b=sb)
-        if epi == "gelu_savegrad":
-            aux_f, aux_s = torch.empty_like(out_f), torch.empty_like(out_f)
-            q, sinv = K.gemm(aq, bq, out_f, M, N, Kd, Kd, Kd, N, bias=bias, act=abi.ACT_GELU_SAVEGRAD, aux_out=aux_f,
-                             ld_aux_out=N, q_next=(hist_f, qfmt), **kw)
-            K.gemm(aq, bq, out_s, M, N, Kd, Kd, Kd, N, bias=bias, act=abi.ACT_GELU_SAVEGRAD, aux_out=aux_s, ld_aux_out=N, **kw)
-            assert torch.equal(aux_f, aux_s)
-        else:
-            aux = _rand((M, N), torch.bfloat16, gen)
-            q, sinv = K.gemm(aq, bq, out_f, M, N, Kd, Kd, Kd, N, act=abi.ACT_MULAUX, aux_in=aux, ld_aux_in=N,
-                             q_next=(hist_f, qfmt), **kw)
-            K.gemm(aq, bq, out_s, M, N, Kd, Kd, Kd, N, act=abi.ACT_MULAUX, aux_in=aux, ld_aux_in=N, **kw)
-        assert torch.equal(out_f, out_s), "the bf16 output must not depend on the fused copy"
-        q_ref, _, sinv_ref = K.fp8_quantize(out_s, qfmt, hist=hist_s)
-        assert sinv.item() == sinv_ref.item(), (call, sinv.item(), sinv_ref.item())
-        assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8)), call
-        assert hist_f.calls == hist_s.calls
-    # the amax handed on: one more stand-alone call on each history gives the same scale
-    probe = _rand((64, N), torch.bfloat16, gen)
-    _, _, s1 = K.fp8_quantize(probe, qfmt, hist=hist_f)
-    _, _, s2 = K.fp8_quantize(probe, qfmt, hist=hist_s)
-    assert s1.item() == s2.item()
