@@ -31,6 +31,21 @@ def test_gemm_descriptor_layout_matches_header(favit):
     # 8 pointers + 21 int64 + 9 int32 + 3 x 4-byte + uint64, naturally aligned
     assert ctypes.sizeof(favit._abi.GemmDesc) == 8 * 8 + 15 * 8 + 9 * 4 + 4 + 4 + 4 + 8 + 2 * 8      # ABI v2: + scale_a, scale_b
     assert favit._abi.GemmDesc.dropout_seed.offset % 8 == 0
+    # and against the C compiler's view of include/favit.h, field by field
+    import os, shutil, subprocess, tempfile
+    if shutil.which("gcc"):
+        fields = [f[0] for f in favit._abi.GemmDesc._fields_]
+        src = "#include <stdio.h>\n#include <stddef.h>\n#include \"favit.h\"\nint main(){printf(\"%zu\", sizeof(favit_gemm_t));" + \
+              "".join(f'printf(" %zu", offsetof(favit_gemm_t, {f}));' for f in fields) + "return 0;}"
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "t.c"), "w") as fh:
+                fh.write(src)
+            inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+            subprocess.check_call(["gcc", "-I", inc, os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+            out = subprocess.check_output([os.path.join(d, "t")], text=True).split()
+        assert int(out[0]) == ctypes.sizeof(favit._abi.GemmDesc)
+        for f, off in zip(fields, out[1:]):
+            assert getattr(favit._abi.GemmDesc, f).offset == int(off), f
 
 
 def test_cfg2_model_init_parity_and_state_dict_keys(favit):
