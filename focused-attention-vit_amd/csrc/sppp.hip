@@ -232,48 +232,53 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 }
 
 // ---- centroids per LABEL (sppp_mhla.py:226-262): exact integer coordinate sums ----
-// Pixels that neighbour each other mostly share a label: a wave reduces (count, sum x, sum y) over the lanes that
-// hold the same label with shuffles and issues ONE set of LDS atomics per distinct label per 64 pixels, instead of
-// three 64-bit LDS atomics per pixel (119 -> ~15 us at 128 images of 224 x 224).  Integer sums: order-independent.
+// One workgroup per image.  Per pixel three 64-bit LDS atomics into one of NC privatised copies of the [S][3] table
+// (copy = lane % NC; rows padded to an odd number of 64-bit words so that the copies of one (label, component) fall
+// into different banks): the wave-wide shuffle reductions per (wave, label) group that round 2 used cost ~80 VALU
+// instructions per group and made this 87 us for 128 images of 224 x 224 (the same finding as in the SLIC assignment,
+// DESIGN.md section 4).  Eight pixels per thread are loaded before any is processed.  Integer sums: order-independent.
+// NC = 16 for S <= 64, 1 above (the table would not fit).
 __global__ __launch_bounds__(1024) void centroid_kernel(const int64_t* __restrict__ seg, float* __restrict__ cent,
-                                                        int HW, int S) {
-  extern __shared__ unsigned long long acc[];     // [S][3]: count, sum x, sum y
-  const int b = blockIdx.x, lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < 3 * S; i += 1024) acc[i] = 0ull;
+                                                        int HW, int S, int NC) {
+  extern __shared__ unsigned long long acc[];     // [NC][3 * S + 1]: count, sum x, sum y per label
+  const int b = blockIdx.x;
+  const int stride = 3 * S + 1;
+  for (int i = threadIdx.x; i < NC * stride; i += 1024) acc[i] = 0ull;
   __syncthreads();
   const int64_t* img = seg + (long)b * HW * HW;
   const long n = (long)HW * HW;
-  const long trips = (n + 1023) / 1024;
-  for (long t = 0; t < trips; ++t) {
-    const long i = t * 1024 + threadIdx.x;
-    int64_t l = -1;
-    if (i < n) l = img[i];
-    bool live = l >= 0 && l < S;
-    const unsigned x = live ? (unsigned)(i % HW) : 0u, y = live ? (unsigned)(i / HW) : 0u;
-    unsigned long long todo = __ballot(live);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int64_t ll = __shfl(l, leader, 64);
-      const bool in = live && l == ll;
-      const unsigned long long grp = __ballot(in);
-      unsigned sx = in ? x : 0u, sy = in ? y : 0u;
+  unsigned long long* mine = acc + (threadIdx.x % NC) * stride;
+  constexpr int U = 8;
+  for (long base = 0; base < n; base += (long)U * 1024) {
+    int64_t l[U];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64); }
-      if (lane == leader) {
-        atomicAdd(&acc[3 * ll], (unsigned long long)__popcll(grp));
-        atomicAdd(&acc[3 * ll + 1], (unsigned long long)sx);
-        atomicAdd(&acc[3 * ll + 2], (unsigned long long)sy);
+    for (int u = 0; u < U; ++u) {
+      const long i = base + (long)u * 1024 + threadIdx.x;
+      l[u] = i < n ? img[i] : (int64_t)-1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (l[u] >= 0 && l[u] < S) {
+        const long i = base + (long)u * 1024 + threadIdx.x;
+        unsigned long long* d = mine + 3 * l[u];
+        atomicAdd(d, 1ull);
+        atomicAdd(d + 1, (unsigned long long)(i % HW));
+        atomicAdd(d + 2, (unsigned long long)(i / HW));
       }
-      todo &= ~grp;
     }
   }
   __syncthreads();
   for (int s = threadIdx.x; s < S; s += 1024) {
-    const unsigned long long c = acc[3 * s];
+    unsigned long long c = 0, sx = 0, sy = 0;
+    for (int k = 0; k < NC; ++k) {
+      c += acc[k * stride + 3 * s];
+      sx += acc[k * stride + 3 * s + 1];
+      sy += acc[k * stride + 3 * s + 2];
+    }
     float cx = 0.5f, cy = 0.5f;
     if (c > 0) {
-      cx = (float)((double)acc[3 * s + 1] / ((double)HW * (double)c));
-      cy = (float)((double)acc[3 * s + 2] / ((double)HW * (double)c));
+      cx = (float)((double)sx / ((double)HW * (double)c));
+      cy = (float)((double)sy / ((double)HW * (double)c));
     }
     cent[((long)b * S + s) * 2 + 0] = cx;
     cent[((long)b * S + s) * 2 + 1] = cy;
@@ -351,7 +356,9 @@ extern "C" int favit_sppp_pool_bwd(const float* dout, const float* emb, const in
 extern "C" int favit_sppp_centroids(const int64_t* seg, float* cent, int32_t B, int32_t HW, int32_t S, void* stream) {
   if (!seg || !cent || B <= 0 || HW <= 0 || S <= 0) return FAVIT_ERR_INVALID;
   if (S > 2048) return FAVIT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(centroid_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * 3 * S, as_stream(stream), seg, cent, HW, S);
+  const int nc = S <= 64 ? 16 : 1;
+  hipLaunchKernelGGL(centroid_kernel, dim3(B), dim3(1024), sizeof(unsigned long long) * (size_t)nc * (3 * S + 1), as_stream(stream),
+                     seg, cent, HW, S, nc);
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }
