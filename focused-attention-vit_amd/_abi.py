@@ -73,6 +73,9 @@ _SIGS = {
     "favit_mhla_fold_bwd_multi": ([i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp], C.c_int),
     "favit_mhla_attn_fwd": ([vp, vp, vp, i32, i32, i32, i32, i32, C.c_int, f32, u64, vp], C.c_int),
     "favit_mhla_attn_bwd": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, C.c_int, f32, u64, vp], C.c_int),
+    "favit_mhla_attn_lse_supported": ([i32, i32, i32, C.c_int], C.c_int),
+    "favit_mhla_attn_fwd_lse": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, C.c_int, f32, u64, vp], C.c_int),
+    "favit_mhla_attn_bwd_lse": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.c_int, f32, u64, vp], C.c_int),
     "favit_sdpa_fwd": ([C.POINTER(SdpaDesc), vp], C.c_int),
     "favit_sdpa_bwd": ([C.POINTER(SdpaDesc), vp], C.c_int),
     "favit_softmax_fwd": ([vp, vp, vp, C.c_int, vp, i64, i64, i32, i64, i32, i32, f32, u64, vp], C.c_int),

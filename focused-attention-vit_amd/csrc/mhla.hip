@@ -267,6 +267,9 @@ struct AttnArgs {
   float keep_scale;
   uint64_t seed;
   const unsigned long long* epoch;   // favit_set_dropout_epoch word (or null)
+  float* lse_out;      // forward (MFMA kernel): log-sum-exp of every (batch, head, row) [B, H, L], or null
+  const float* lse;    // backward, "saved statistics" kernel: the forward's lse ...
+  const void* o;       // ... and the forward's output [B*L, D] (delta of the halo rows = dO . O)
 };
 
 // scores + softmax of one query row (8 lanes own the row; every lane ends with all p[w])
@@ -666,6 +669,7 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
   }
   lsum = quad16_sum(lsum);
   const float inv_l = 1.0f / lsum;
+  if (a.lse_out && g == 0 && qvalid) a.lse_out[((long)b * a.H + head) * L + i] = mx + __logf(lsum);
   bf16x8 pf;
 #pragma unroll
   for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)(sc[e] * inv_l * kw[e]);
@@ -1308,6 +1312,384 @@ __global__ __launch_bounds__(256) void mhla_bwd_mfma2_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
+// MFMA backward with SAVED statistics (round 3; bf16, hd = 64, W <= 11, L >= 2h + 2).  Same two owner passes as above,
+// but the forward hands over lse per (batch, head, row) and its output O, so a query row outside the block never
+// needs its softmax recomputed: P = mult * exp(s - lse_i) directly, and delta_i = sum_w P_w dP_w = dO_i . O_i is an
+// 64-term dot product for the <= 4h + 1 halo / wrap rows of a block (owned rows keep the exact fp32 sum of pass 1).
+//   * pass 1 runs over the OWNED 16-row tiles only (the table-free kernel above also ran the halo tiles: 15-17 query
+//     tiles per (batch, head) at L = 197 against 13 here), rows [r0 - h, r1 + h) are staged once for all four images
+//     (K~/V~ needed [r0 - 2h, r1 + 2h) before) and blocks are whole tiles: rb = 64 rows, one wave per tile in both
+//     passes;
+//   * 128-byte LDS rows with the 16-byte chunks XOR-swizzled by the row index instead of 144-byte padded rows:
+//     (rb + 2h + 2) K~/V~ rows and (rb + 4h + 1) Q / dO rows = 38.8 KiB at W = 7 -> four workgroups per CU.
+// 271 MB of algorithmic traffic + 6 % for the halo rows; see DESIGN.md for the measured split.
+// ---------------------------------------------------------------------------------
+// PairStager for a run-time thread count and swizzled 128-byte rows: load() issues every request, store() writes LDS.
+//  * addresses = a workgroup-uniform base + a 32-bit byte offset per lane (the SGPR-base form of global_load: one
+//    multiply-add per chunk instead of 64-bit pointer arithmetic -- staging was a third of the kernel's VALU work);
+//  * store() is branch-free: chunks past the end (and rows `keep` rejects) go to a 1-KiB `dump` area, one slot per
+//    lane.  A predicated store lets the compiler sink each load into its store's block: one global round trip per
+//    chunk, one after the other (which is how the older kernels above stage, as their disassembly shows).
+template <int NCH>
+struct PairStager128 {
+  uint4 ra[NCH], rb[NCH];
+  // row_off_a / row_off_b: byte offset of LDS row s from base_a / base_b
+  template <typename FA, typename FB>
+  __device__ __forceinline__ void load(int nrows, int tid, int nthr, const char* base_a, const char* base_b, FA row_off_a,
+                                       FB row_off_b) {
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int c = min(tid + nthr * it, nrows * 8 - 1);     // clamped: unconditional load
+      const uint32_t ch = (uint32_t)(c & 7) * 16u;
+      ra[it] = *reinterpret_cast<const uint4*>(base_a + (row_off_a(c >> 3) + ch));
+      rb[it] = *reinterpret_cast<const uint4*>(base_b + (row_off_b(c >> 3) + ch));
+    }
+  }
+  template <typename FP>
+  __device__ __forceinline__ void store(char* lds_a, char* lds_b, char* dump, int nrows, int tid, int nthr, FP keep) const {
+    char* mine = dump + (tid & 63) * 16;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int c = tid + nthr * it;
+      const bool ok = c < nrows * 8 && keep(c >> 3);
+      const int o = (c >> 3) * 128 + ((((c & 7) ^ (c >> 3)) & 7) << 4);
+      *reinterpret_cast<uint4*>(ok ? lds_a + o : mine) = ra[it];
+      *reinterpret_cast<uint4*>(ok ? lds_b + o : mine) = rb[it];
+    }
+  }
+};
+
+__device__ __forceinline__ int swz128(int slot, int boff) {        // byte `boff` (< 128) of LDS row `slot`
+  return slot * 128 + ((((boff >> 4) ^ slot) & 7) << 4) + (boff & 15);
+}
+
+template <bool PLAIN, int NIT>           // NIT: 16-byte chunks per thread and image pair (3: two or more tiles per block, W <= 7)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void mhla_bwd_lse_kernel(AttnArgs a) {
+  constexpr int HD = 64;
+  if (a.thresh) a.seed = favit_eff_seed(a.seed, a.epoch);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, qi = lane & 15, q4 = qi >> 2, p4 = qi & 3;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int L = a.L, W = a.W, h = W >> 1, D = a.H * HD;
+  const int r0 = blockIdx.x * a.rb, r1 = min(L, r0 + a.rb);
+  const long ld = 3L * D, tok0 = (long)b * L;
+  const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
+  const bf16_t* dout = reinterpret_cast<const bf16_t*>(a.dout);
+  const bf16_t* fo = reinterpret_cast<const bf16_t*>(a.o);
+  bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.out);
+  const float* lse_g = a.lse + ((long)b * a.H + head) * L;
+
+  // Images.  Main rows [qm_lo, qm_hi) of all four matrices share their slots; then K~/V~: key 0, key L-1 (the wrap
+  // keys of pass 1); Q/dO: rows 0..h (they END-pad onto key L-1; only staged by the block that owns it) and rows
+  // L-h..L-1 (they FRONT-pad onto key 0).
+  const int qm_lo = max(0, r0 - h), qm_hi = min(L, r1 + h), nm = qm_hi - qm_lo;
+  const bool has_hx = r1 >= L, has_tx = r0 == 0;
+  const int tx_lo = L - h;
+  const int cap_kv = a.rb + 2 * h + 2, cap_q = a.rb + 4 * h + 1;
+  char* ldsK = smem;
+  char* ldsV = ldsK + cap_kv * 128;
+  char* ldsQ = ldsV + cap_kv * 128;
+  char* ldsG = ldsQ + cap_q * 128;
+  float* stat = reinterpret_cast<float*>(ldsG + cap_q * 128);          // [cap_q][2]: lse, delta
+  const int nkv = nm + 2, nq = nm + 2 * h + 1;
+  auto q_row = [&](int s) {                                            // -1: slot not used by this block
+    if (s < nm) return qm_lo + s;
+    const int e = s - nm;
+    if (e <= h) return has_hx ? e : -1;
+    return has_tx ? tx_lo + (e - h - 1) : -1;
+  };
+  {
+    PairStager128<NIT> skv, sqg;
+    const uint32_t ldb = (uint32_t)ld * 2u, ldg = (uint32_t)D * 2u;      // row pitches in bytes (qkv, dout)
+    const char* base_q = reinterpret_cast<const char*>(qkv + tok0 * ld + head * HD);
+    const char* base_g = reinterpret_cast<const char*>(dout + tok0 * (long)D + head * HD);
+    auto kv_row = [&](int s) { return (uint32_t)(s < nm ? qm_lo + s : (s == nm ? 0 : L - 1)); };
+    // (branch-free: the wrap slots of a block that does not use them load rows 0..h / L-h.. all the same)
+    auto q_src = [&](int s) { const int e = s - nm; return (uint32_t)(s < nm ? qm_lo + s : (e <= h ? e : tx_lo + (e - h - 1))); };
+    skv.load(nkv, tid, nthr, base_q + D * 2, base_q + D * 4, [&](int s) { return kv_row(s) * ldb; },
+             [&](int s) { return kv_row(s) * ldb; });
+    sqg.load(nq, tid, nthr, base_q, base_g, [&](int s) { return q_src(s) * ldb; }, [&](int s) { return q_src(s) * ldg; });
+    // lse of every Q / dO slot: one slot per thread (nq <= 64 * waves), requested with the rows and branch-free as well
+    const bool lse_ok = tid < nq && ((tid < nm) | (tid - nm <= h ? has_hx : has_tx));
+    const float lse_v = lse_g[lse_ok ? q_src(tid) : 0u];
+    char* dump = reinterpret_cast<char*>(stat + 2 * cap_q);
+    *(lse_ok ? stat + 2 * tid : reinterpret_cast<float*>(dump) + tid) = lse_v;
+    skv.store(ldsK, ldsV, dump, nkv, tid, nthr, [&](int) { return true; });
+    sqg.store(ldsQ, ldsG, dump, nq, tid, nthr, [&](int s) { return (s < nm) | (s - nm <= h ? has_hx : has_tx); });
+  }
+  // delta of the rows this block does not own: their O rows are requested now and used after pass 1.  Candidate x:
+  // h rows below r0, h rows from r1 up, the 2h + 1 wrap rows; 8 lanes (16 bytes each) per row.
+  constexpr int NXP = NIT == 3 ? 1 : 3;      // passes of nthr / 8 rows (NIT = 3: >= 16 rows per pass, <= 13 candidates;
+                                             // 64 threads at W = 11: 21 candidates in passes of 8)
+  const int nx = 4 * h + 1;
+  auto x_slot = [&](int x) {                                            // -1: nothing to do
+    if (x < h) return x < r0 - qm_lo ? x : -1;
+    if (x < 2 * h) { const int s = (r1 - qm_lo) + (x - h); return s < nm ? s : -1; }
+    const int s = nm + (x - 2 * h);
+    return q_row(s) >= 0 ? s : -1;
+  };
+  uint4 ro[NXP];
+#pragma unroll
+  for (int k = 0; k < NXP; ++k) {
+    const int x = (tid >> 3) + k * (nthr >> 3);
+    const int s = x < nx ? x_slot(x) : -1;
+    ro[k] = *reinterpret_cast<const uint4*>(fo + (tok0 + (s >= 0 ? q_row(s) : r0)) * (long)D + head * HD + (tid & 7) * 8);
+  }
+  __syncthreads();
+#ifdef FAVIT_PROBE
+  if (a.dbg & 2) return;                                 // probe: staging only
+  const bool probe_nostore = (a.dbg & 1) != 0;
+#else
+  constexpr bool probe_nostore = false;
+#endif
+
+  const float inv_sq = 0.125f;                           // 1 / sqrt(64)
+  // ---------------- pass 1: the owned query tiles ----------------
+  if (r0 + 16 * wave < r1) {
+    const int t0 = r0 + 16 * wave;
+    const int i = t0 + qi;
+    SlotInfo si;
+    si.init(min(i, L - 1), L, W, h);
+    auto kslot = [&](int slot) {                                        // image row of a key slot of this tile
+      if (slot == 31) return nm + 1;
+      if (slot >= 16 + 2 * h) return nm;                                // slot 30 (key 0) and the unused slots
+      return min(max(t0 - h + slot, qm_lo), qm_hi - 1) - qm_lo;
+    };
+    const int qslot = min(t0 - qm_lo + qi, nm - 1);
+    const int krow0 = kslot(qi), krow1 = kslot(16 + qi);
+    f32x4 S[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 dP[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      const int off = (32 * ks + 8 * g) * 2;
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(ldsQ + swz128(qslot, off));
+      const bf16x8 gf = *reinterpret_cast<const bf16x8*>(ldsG + swz128(qslot, off));
+      const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(ldsK + swz128(krow0, off));
+      const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(ldsK + swz128(krow1, off));
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(ldsV + swz128(krow0, off));
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(ldsV + swz128(krow1, off));
+      S[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, S[0], 0, 0, 0);
+      S[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf, S[1], 0, 0, 0);
+      dP[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, gf, dP[0], 0, 0, 0);
+      dP[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, gf, dP[1], 0, 0, 0);
+    }
+    const float lse_i = stat[2 * qslot];
+    float pn[8], mult[8], dpn[8];
+    // interior tile (wave-uniform): every row has its full window of W distinct keys, no wrap slots, no padding
+    const bool interior = PLAIN && t0 >= h && t0 + 15 + h <= L - 1;
+    if (interior) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int slot = 16 * (e >> 2) + 4 * g + (e & 3);
+        const int d = slot - h - qi;                                    // key - query
+        const bool in = (slot < 16 + 2 * h) && (d >= -h) && (d <= h);
+        mult[e] = in ? 1.f : 0.f;
+        pn[e] = in ? __expf(S[e >> 2][e & 3] * inv_sq - lse_i) : 0.f;
+        dpn[e] = mult[e] * dP[e >> 2][e & 3];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int kt = e >> 2, r = e & 3;
+        const int slot = 16 * kt + 4 * g + r;
+        int j, mu, w0;
+        if (slot < 16 + 2 * h && slot < 30) {
+          j = t0 - h + slot;
+          mu = (j >= si.lo && j < si.hi) ? 1 : 0;
+          w0 = (si.lo == 0 || si.pad == 0) ? (j - si.lo) : si.pad + (j - si.lo);
+        } else if (slot == 30) {
+          j = 0; mu = si.front_pad; w0 = 0;
+        } else if (slot == 31) {
+          j = L - 1; mu = si.end_pad; w0 = si.n;
+        } else {
+          j = 0; mu = 0; w0 = 0;
+        }
+        if (!PLAIN && mu > 0 && a.mask && a.mask[((long)b * L + si.i) * L + j] == 0) mu = 0;
+        float kwe = (float)mu;
+        if (!PLAIN && a.thresh && mu > 0) {
+          kwe = 0.f;
+          for (int c = 0; c < mu; ++c) {
+            const uint64_t idx = (((uint64_t)b * a.H + head) * L + si.i) * W + (w0 + c);
+            kwe += favit_keep(a.seed, idx, a.thresh) ? a.keep_scale : 0.f;
+          }
+        }
+        mult[e] = (float)mu;
+        pn[e] = mu > 0 ? __expf(S[kt][r] * inv_sq - lse_i) : 0.f;      // single-copy probability
+        dpn[e] = kwe * dP[kt][r];
+      }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dot = fmaf(pn[e], dpn[e], dot);
+    dot = quad16_sum(dot);
+    const bool own = i < r1;
+    if (g == 0 && own) stat[2 * qslot + 1] = dot;
+    bf16x8 dsf;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dsf[e] = (bf16_t)((pn[e] * dpn[e] - mult[e] * pn[e] * dot) * inv_sq);
+    const int vrow0 = kslot(4 * g + q4), vrow1 = kslot(16 + 4 * g + q4);
+    bf16_t* dqrow = dqkv + (tok0 + si.i) * ld + head * HD;
+    f32x4 oq[HD / 16];
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      const int coff = tr_col(dt, p4) * 2;
+      const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + swz128(vrow0, coff)));
+      const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsK + swz128(vrow1, coff)));
+      s16x8 kk;
+      kk[0] = lo4[0]; kk[1] = lo4[1]; kk[2] = lo4[2]; kk[3] = lo4[3];
+      kk[4] = hi4[0]; kk[5] = hi4[1]; kk[6] = hi4[2]; kk[7] = hi4[3];
+      oq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kk), dsf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    if (own && !(probe_nostore && oq[0][0] != 12345.f)) store_rows16<HD>(dqrow, oq, g);
+  }
+  // delta = dO . O of the rows owned by other blocks
+#pragma unroll
+  for (int k = 0; k < NXP; ++k) {
+    const int x = (tid >> 3) + k * (nthr >> 3);
+    const int s = x < nx ? x_slot(x) : -1;
+    float d = 0.f;
+    if (s >= 0) {
+      const uint4 gd = *reinterpret_cast<const uint4*>(ldsG + swz128(s, (tid & 7) * 16));
+      const uint32_t ow[4] = {ro[k].x, ro[k].y, ro[k].z, ro[k].w}, gw[4] = {gd.x, gd.y, gd.z, gd.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        d = fmaf(__uint_as_float(ow[c] << 16), __uint_as_float(gw[c] << 16), d);
+        d = fmaf(__uint_as_float(ow[c] & 0xffff0000u), __uint_as_float(gw[c] & 0xffff0000u), d);
+      }
+    }
+    d = dpp_sum8(d);
+    if (s >= 0 && (tid & 7) == 0) stat[2 * s + 1] = d;
+  }
+  __syncthreads();
+
+  // ---------------- pass 2: the owned key tiles ----------------
+  const int k0 = r0 + 16 * wave;
+  if (k0 >= r1) return;
+  const int j = k0 + qi;                                  // this lane's key (B-operand column)
+  const int jc = min(j, L - 1);
+  const bool has0 = (k0 == 0), hasL = (L - 1 >= k0 && L - 1 < k0 + 16);
+  const int nband = 16 + 2 * h;
+  const int nhx = hasL ? h + 1 : 0;                       // rows 0..h END-pad onto key L-1
+  auto main_slot = [&](int i) { return min(max(i, qm_lo), qm_hi - 1) - qm_lo; };
+  // query slot -> (query row, image / statistics slot, kind): 0 band, 1 END-pad row, 2 FRONT-pad row, 3 unused
+  auto qs_row = [&](int qs, int& row, int& tslot, int& kind) {
+    if (qs < nband) {
+      kind = 0;
+      row = k0 - h + qs;
+      tslot = main_slot(row);
+    } else if (qs < nband + nhx) {
+      kind = 1;
+      row = qs - nband;
+      tslot = nm + row;
+    } else {
+      const int k = qs - nband - nhx;
+      kind = 2;
+      row = tx_lo + k;
+      if (!has0 || k >= h) { kind = 3; row = 0; tslot = main_slot(k0); return; }
+      tslot = nm + h + 1 + k;
+    }
+  };
+  const bool interior_keys = PLAIN && !has0 && !hasL;       // wave-uniform: band query slots only, multiplicity 0 / 1
+  auto img_slot = [&](int qs) {                             // Q / dO image row (and statistics slot) of a query slot
+    if (interior_keys) return main_slot(k0 - h + qs);       // (clamped: slots past the band carry multiplicity 0)
+    int row, tslot, kind;
+    qs_row(qs, row, tslot, kind);
+    return tslot;
+  };
+  // S^T[qs][key] = Q_qs . K_key,  dP^T[qs][key] = dO_qs . V_key   (A = the query slot rows, B = this lane's key row)
+  f32x4 T1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  f32x4 T2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  {
+    const int ts0 = img_slot(qi), ts1 = img_slot(16 + qi);
+    const int kj = main_slot(jc);
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      const int off = (32 * ks + 8 * g) * 2;
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ldsK + swz128(kj, off));
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(ldsV + swz128(kj, off));
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(ldsQ + swz128(ts0, off));
+      const bf16x8 qb = *reinterpret_cast<const bf16x8*>(ldsQ + swz128(ts1, off));
+      const bf16x8 ga = *reinterpret_cast<const bf16x8*>(ldsG + swz128(ts0, off));
+      const bf16x8 gb = *reinterpret_cast<const bf16x8*>(ldsG + swz128(ts1, off));
+      T1[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, T1[0], 0, 0, 0);
+      T1[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb, kf, T1[1], 0, 0, 0);
+      T2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, vf, T2[0], 0, 0, 0);
+      T2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb, vf, T2[1], 0, 0, 0);
+    }
+  }
+  // the lane holds query slots 16 st + 4g + r (e = 4 st + r) of its key: exactly the k-slice of the next MFMAs
+  bf16x8 wds, wp;
+  if (interior_keys) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int qs = 16 * (e >> 2) + 4 * g + (e & 3);
+      const int row = k0 - h + qs, d = qs - h - qi;                    // query row, query - key
+      const int tslot = min(max(row, qm_lo), qm_hi - 1) - qm_lo;
+      const bool in = (qs < nband) && (row < L) && (j < L) && (d >= -h) && (d <= h);
+      const float lse = stat[2 * tslot], dl = stat[2 * tslot + 1];
+      const float pn = in ? __expf(T1[e >> 2][e & 3] * inv_sq - lse) : 0.f;
+      wds[e] = (bf16_t)(pn * (T2[e >> 2][e & 3] - dl) * inv_sq);
+      wp[e] = (bf16_t)pn;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int row, tslot, kind;
+      qs_row(16 * (e >> 2) + 4 * g + (e & 3), row, tslot, kind);
+      int mu = 0, w0 = 0;
+      if (j < L && row >= 0 && row < L && kind != 3) {
+        const int lo = max(0, row - h), hi = min(L, row + h + 1), n = hi - lo, pad = W - n;
+        if (kind == 0) {
+          if (j >= lo && j < hi) { mu = 1; w0 = (lo == 0 || pad == 0) ? (j - lo) : pad + (j - lo); }
+        } else if (kind == 1) {
+          if (j == L - 1 && lo == 0) { mu = pad; w0 = n; }              // END padding of the rows whose window starts at 0
+        } else {
+          if (j == 0 && lo > 0) { mu = pad; w0 = 0; }                   // FRONT padding
+        }
+        if (!PLAIN && mu > 0 && a.mask && a.mask[((long)b * L + row) * L + j] == 0) mu = 0;
+      }
+      float kwe = (float)mu;
+      if (!PLAIN && a.thresh && mu > 0) {
+        kwe = 0.f;
+        for (int c = 0; c < mu; ++c) {
+          const uint64_t idx = (((uint64_t)b * a.H + head) * L + row) * W + (w0 + c);
+          kwe += favit_keep(a.seed, idx, a.thresh) ? a.keep_scale : 0.f;
+        }
+      }
+      const float lse = stat[2 * tslot], dl = stat[2 * tslot + 1];
+      const float pn = mu > 0 ? __expf(T1[e >> 2][e & 3] * inv_sq - lse) : 0.f;
+      wds[e] = (bf16_t)(pn * (kwe * T2[e >> 2][e & 3] - (float)mu * dl) * inv_sq);
+      wp[e] = (bf16_t)(pn * kwe);
+    }
+  }
+  // A fragments: Q^T / dO^T rows of query slots 4g+q4 and 16+4g+q4 (every lane supplies one row address)
+  const int ta = img_slot(4 * g + q4), tb = img_slot(16 + 4 * g + q4);
+  const bool jvalid = j < r1;
+  bf16_t* dkrow = dqkv + (tok0 + jc) * ld + D + head * HD;
+  bf16_t* dvrow = dkrow + D;
+  f32x4 okk[HD / 16], ovv[HD / 16];
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) {
+    const int coff = tr_col(dt, p4) * 2;
+    const s16x4 qa = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsQ + swz128(ta, coff)));
+    const s16x4 qb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsQ + swz128(tb, coff)));
+    const s16x4 ga = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsG + swz128(ta, coff)));
+    const s16x4 gb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_t)(ldsG + swz128(tb, coff)));
+    s16x8 qq, gg;
+    qq[0] = qa[0]; qq[1] = qa[1]; qq[2] = qa[2]; qq[3] = qa[3]; qq[4] = qb[0]; qq[5] = qb[1]; qq[6] = qb[2]; qq[7] = qb[3];
+    gg[0] = ga[0]; gg[1] = ga[1]; gg[2] = ga[2]; gg[3] = ga[3]; gg[4] = gb[0]; gg[5] = gb[1]; gg[6] = gb[2]; gg[7] = gb[3];
+    okk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, qq), wds, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    ovv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, gg), wp, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+  if (jvalid && !(probe_nostore && okk[0][0] != 12345.f)) {
+    store_rows16<HD>(dkrow, okk, g);
+    store_rows16<HD>(dvrow, ovv, g);
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // latent_proj fold (weight space, tiny): LDS-tiled, register-blocked small GEMMs so each launch is
 // a few microseconds.
 //   Weff[s,h] = Wl . Wqkv[s,h],  beff[s,h] = Wl . bqkv[s,h] + bl      (s in {k, v})
@@ -1579,8 +1961,16 @@ int dispatch_dpl(bool bwd, const AttnArgs& a, hipStream_t st) {
   }
 }
 
+// the saved-statistics backward (mhla_bwd_lse_kernel) and the forward that feeds it
+bool lse_path_ok(int L, int hd, int W, int dtype) {
+  const int h = W / 2;
+  return dtype == FAVIT_BF16 && hd == 64 && W > 0 && (W & 1) && (W <= 7 || (W <= 11 && L > 16)) && L >= 2 * h + 2 &&
+         getenv("FAVIT_MHLA_VALU") == nullptr && getenv("FAVIT_MHLA_NO_LSE") == nullptr;
+}
+
 int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uint8_t* mask, int B, int L, int H, int hd,
-               int W, int dtype, float p, uint64_t seed, void* stream) {
+               int W, int dtype, float p, uint64_t seed, void* stream, const void* fwd_o = nullptr,
+               const float* lse_in = nullptr, float* lse_out = nullptr) {
   if (!qkv || !out || (bwd && !dout) || B <= 0 || L <= 0 || H <= 0 || hd <= 0) return FAVIT_ERR_INVALID;
   if (W <= 0 || (W & 1) == 0) return FAVIT_ERR_INVALID;      // even windows crash the reference (mhla.py:83)
   if (W > 15) return FAVIT_ERR_UNSUPPORTED;
@@ -1588,6 +1978,8 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
   AttnArgs a;
   a.qkv = qkv; a.dout = dout; a.out = out; a.mask = mask;
   a.B = B; a.L = L; a.H = H; a.hd = hd; a.W = W;
+  a.lse_out = lse_out; a.lse = lse_in; a.o = fwd_o;
+  if (lse_out && (bwd || !lse_path_ok(L, hd, W, dtype))) return FAVIT_ERR_UNSUPPORTED;
   {
     // backward row block: as many key rows as the fixed LDS regions allow (64 query / dO rows incl.
     // the wrap rows, 80 K~/V~ rows incl. halo and edges), then balanced over the blocks of L
@@ -1624,6 +2016,31 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
     if (hd == 32) { if (plain) hipLaunchKernelGGL((mhla_fwd_mfma_kernel<32, true>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((mhla_fwd_mfma_kernel<32, false>), grid, dim3(256), lds, st, a); }
     else if (hd == 64) { if (plain) hipLaunchKernelGGL((mhla_fwd_mfma_kernel<64, true>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((mhla_fwd_mfma_kernel<64, false>), grid, dim3(256), lds, st, a); }
     else { if (plain) hipLaunchKernelGGL((mhla_fwd_mfma_kernel<128, true>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((mhla_fwd_mfma_kernel<128, false>), grid, dim3(256), lds, st, a); }
+    FAVIT_CHECK_LAUNCH();
+    return FAVIT_OK;
+  }
+  // bf16 backward with the forward's statistics (mhla_bwd_lse_kernel): whole-tile row blocks, one wave per 16 rows
+  if (bwd && lse_in && fwd_o) {
+    if (!lse_path_ok(L, hd, W, dtype)) return FAVIT_ERR_UNSUPPORTED;
+    const int h = W / 2;
+    // three tiles per block: 31.5 KiB of LDS = five workgroups per CU (measured at L = 197: 65.9 us against 71.2 with
+    // four tiles / 39.8 KiB / four per CU and 68.3 with two)
+    int nw = (L + 15) / 16 < 3 ? (L + 15) / 16 : 3;
+    { const char* e = getenv("FAVIT_MHLA_LSE_WAVES"); if (e && atoi(e) >= 1 && atoi(e) <= 4 && atoi(e) <= (L + 15) / 16) nw = atoi(e); }
+    AttnArgs a3 = a;
+    a3.rb = 16 * nw;
+    const int cap_kv = a3.rb + 2 * h + 2, cap_q = a3.rb + 4 * h + 1;
+    const size_t lds = (size_t)(2 * cap_kv + 2 * cap_q) * 128 + (size_t)cap_q * 8 + 1024;     // images, statistics, dump
+    dim3 grid((L + a3.rb - 1) / a3.rb, H, B);
+    const bool plain = mask == nullptr && a3.thresh == 0;
+    const bool three = cap_kv * 8 <= 3 * 64 * nw && cap_q * 8 <= 3 * 64 * nw;         // chunks per thread and image pair
+    if (three) {
+      if (plain) hipLaunchKernelGGL((mhla_bwd_lse_kernel<true, 3>), grid, dim3(64 * nw), lds, st, a3);
+      else hipLaunchKernelGGL((mhla_bwd_lse_kernel<false, 3>), grid, dim3(64 * nw), lds, st, a3);
+    } else {
+      if (plain) hipLaunchKernelGGL((mhla_bwd_lse_kernel<true, 5>), grid, dim3(64 * nw), lds, st, a3);
+      else hipLaunchKernelGGL((mhla_bwd_lse_kernel<false, 5>), grid, dim3(64 * nw), lds, st, a3);
+    }
     FAVIT_CHECK_LAUNCH();
     return FAVIT_OK;
   }
@@ -1697,6 +2114,24 @@ extern "C" int favit_mhla_attn_bwd(const void* qkv, const void* dout, void* dqkv
                                    int32_t L, int32_t H, int32_t hd, int32_t W, int dtype, float dropout_p,
                                    uint64_t seed, void* stream) {
   return attn_entry(true, qkv, dout, dqkv, mask, B, L, H, hd, W, dtype, dropout_p, seed, stream);
+}
+
+extern "C" int favit_mhla_attn_lse_supported(int32_t L, int32_t hd, int32_t W, int dtype) {
+  return lse_path_ok(L, hd, W, dtype) ? 1 : 0;
+}
+
+extern "C" int favit_mhla_attn_fwd_lse(const void* qkv, void* out, float* lse, const uint8_t* mask, int32_t B, int32_t L,
+                                       int32_t H, int32_t hd, int32_t W, int dtype, float dropout_p, uint64_t seed,
+                                       void* stream) {
+  if (!lse) return FAVIT_ERR_INVALID;
+  return attn_entry(false, qkv, nullptr, out, mask, B, L, H, hd, W, dtype, dropout_p, seed, stream, nullptr, nullptr, lse);
+}
+
+extern "C" int favit_mhla_attn_bwd_lse(const void* qkv, const void* dout, const void* o, const float* lse, void* dqkv,
+                                       const uint8_t* mask, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t W,
+                                       int dtype, float dropout_p, uint64_t seed, void* stream) {
+  if (!o || !lse) return FAVIT_ERR_INVALID;
+  return attn_entry(true, qkv, dout, dqkv, mask, B, L, H, hd, W, dtype, dropout_p, seed, stream, o, lse, nullptr);
 }
 
 extern "C" int favit_mhla_fold_fwd(const float* wqkv, const float* bqkv, const float* wl, const float* bl, void* weff,

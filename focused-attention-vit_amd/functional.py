@@ -614,10 +614,13 @@ class MHLAChain:
         sp = _seed() if pp > 0 else 0
         weff, beff = pre if pre is not None else K.mhla_fold_fwd(wqkv, bqkv, wl, bl, H, xn.dtype)
         qkv = lin_fwd(xn, weff, beff, M, 3 * D, D, xn.dtype, site=wqkv)
-        o = K.mhla_attn_fwd(qkv, B, L, H, hd, self.W, mask, pa, sa)
+        # training: the forward also leaves lse per row, and backward runs the saved-statistics kernel (None where
+        # that kernel does not apply: other head sizes, fp32)
+        o, lse = K.mhla_attn_fwd(qkv, B, L, H, hd, self.W, mask, pa, sa, want_lse=True) if training else \
+            (K.mhla_attn_fwd(qkv, B, L, H, hd, self.W, mask, pa, sa), None)
         wp_c = wcast(wp)
         y = lin_fwd(o, wp_c, bp.detach(), M, D, D, torch.float32, residual=residual, drop=(pp, sp), site=wp)
-        return y, (xn, weff, qkv, o, wp_c, mask, B, L, pa, sa, pp, sp, prm)
+        return y, (xn, weff, qkv, o, wp_c, mask, B, L, pa, sa, pp, sp, prm, lse)
 
     @staticmethod
     def out_dropout(saved):
@@ -625,14 +628,14 @@ class MHLAChain:
         return saved[10], saved[11]
 
     def bwd(self, saved, dy_lp, premasked=False):
-        xn, weff, qkv, o, wp_c, mask, B, L, pa, sa, pp, sp, prm = saved
+        xn, weff, qkv, o, wp_c, mask, B, L, pa, sa, pp, sp, prm, lse = saved
         wqkv, bqkv, wl, bl, wp, bp = prm
         M, D = xn.shape
         H, hd = self.H, D // self.H
         dym = K.dropout(dy_lp, pp, sp) if (pp > 0 and not premasked) else dy_lp
         do = lin_bwd_x(dym, wp_c, M, D, D, xn.dtype, site=wp)
         dwp, dbp = lin_bwd_w(dym, o, M, D, D, wp=wp, bp=bp)
-        dqkv = K.mhla_attn_bwd(qkv, do, B, L, H, hd, self.W, mask, pa, sa)
+        dqkv = K.mhla_attn_bwd(qkv, do, B, L, H, hd, self.W, mask, pa, sa, o=o if lse is not None else None, lse=lse)
         dxn = lin_bwd_x(dqkv, weff, M, 3 * D, D, xn.dtype, site=wqkv)
         dweff, dbeff = lin_bwd_w(dqkv, xn, M, 3 * D, D)
         flush_wgrads()                      # dW2, dW1, dWproj, dWeff of this block: one grouped launch

@@ -369,17 +369,35 @@ def mhla_fold_bwd_multi(entries, H):
         _abi.check(_abi.lib().favit_mhla_fold_bwd_multi(n, *cols, D, H, _st()), "favit_mhla_fold_bwd_multi")
 
 
-def mhla_attn_fwd(qkv, B, L, H, hd, W, mask=None, p=0.0, seed=0):
+def mhla_attn_lse_supported(L, hd, W, dtype) -> bool:
+    """Do favit_mhla_attn_fwd_lse / _bwd_lse take this shape (bf16, hd = 64, odd W <= 7 or <= 11 with L > 16)?"""
+    code = {torch.float32: _abi.F32, torch.bfloat16: _abi.BF16}.get(dtype)
+    return code is not None and bool(_abi.lib().favit_mhla_attn_lse_supported(L, hd, W, code))
+
+
+def mhla_attn_fwd(qkv, B, L, H, hd, W, mask=None, p=0.0, seed=0, want_lse=False):
+    """Attention core; with want_lse returns (out, lse fp32 [B, H, L]) -- lse is None where the saved-statistics
+    backward does not apply (the caller then uses mhla_attn_bwd without it)."""
     require_gpu(qkv, mask)
     out = torch.empty((B * L, H * hd), dtype=qkv.dtype, device=qkv.device)
+    if want_lse and mhla_attn_lse_supported(L, hd, W, qkv.dtype):
+        lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+        _abi.check(_abi.lib().favit_mhla_attn_fwd_lse(_p(qkv), _p(out), _p(lse), _p(mask), B, L, H, hd, W, dt(qkv), p,
+                                                      seed, _st()), "favit_mhla_attn_fwd_lse")
+        return out, lse
     _abi.check(_abi.lib().favit_mhla_attn_fwd(_p(qkv), _p(out), _p(mask), B, L, H, hd, W, dt(qkv), p, seed, _st()),
                "favit_mhla_attn_fwd")
-    return out
+    return (out, None) if want_lse else out
 
 
-def mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask=None, p=0.0, seed=0):
-    require_gpu(qkv, dout, mask)
+def mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask=None, p=0.0, seed=0, o=None, lse=None):
+    """dqkv of the attention core; with the forward's output and lse the saved-statistics kernel runs."""
+    require_gpu(qkv, dout, mask, o, lse)
     dqkv = torch.empty_like(qkv)
+    if o is not None and lse is not None:
+        _abi.check(_abi.lib().favit_mhla_attn_bwd_lse(_p(qkv), _p(dout), _p(o), _p(lse), _p(dqkv), _p(mask), B, L, H, hd,
+                                                      W, dt(qkv), p, seed, _st()), "favit_mhla_attn_bwd_lse")
+        return dqkv
     _abi.check(_abi.lib().favit_mhla_attn_bwd(_p(qkv), _p(dout), _p(dqkv), _p(mask), B, L, H, hd, W, dt(qkv), p, seed,
                                               _st()), "favit_mhla_attn_bwd")
     return dqkv

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FAVIT_ABI_VERSION 5
+#define FAVIT_ABI_VERSION 6
 #define FAVIT_FP8_AMAX_SLOTS 256   /* partial maxima per tensor with delayed fp8 scaling (favit_fp8_quantize) */
 
 enum { FAVIT_F32 = 0, FAVIT_BF16 = 1, FAVIT_FP8 = 2 };
@@ -222,6 +222,18 @@ int favit_mhla_attn_fwd(const void* qkv, void* out, const uint8_t* mask, int32_t
 int favit_mhla_attn_bwd(const void* qkv, const void* dout, void* dqkv, const uint8_t* mask, int32_t B, int32_t L,
                         int32_t H, int32_t hd, int32_t W, int dtype, float dropout_p, uint64_t seed,
                         void* stream);
+/* The same attention core with the forward's softmax statistics handed to backward (ABI 6): `lse` fp32 [B, H, L] =
+ * log sum_w exp(s_w) of every row's window (pad copies counted, mask applied), `o` = the forward's output.  With them
+ * backward recomputes no softmax for rows outside a workgroup's block (P = exp(s - lse); delta = dO . O for the halo
+ * rows: o is in bf16, so delta of those rows carries its rounding, ~2^-9 relative) -- the cfg2 launch takes @@ us
+ * against 79.  favit_mhla_attn_lse_supported: 1 where both entry points run (bf16, hd = 64, odd W <= 7, or <= 11 with
+ * L > 16; L >= W + 1), else the callers use the pair above. */
+int favit_mhla_attn_lse_supported(int32_t L, int32_t hd, int32_t W, int dtype);
+int favit_mhla_attn_fwd_lse(const void* qkv, void* out, float* lse, const uint8_t* mask, int32_t B, int32_t L, int32_t H,
+                            int32_t hd, int32_t W, int dtype, float dropout_p, uint64_t seed, void* stream);
+int favit_mhla_attn_bwd_lse(const void* qkv, const void* dout, const void* o, const float* lse, void* dqkv,
+                            const uint8_t* mask, int32_t B, int32_t L, int32_t H, int32_t hd, int32_t W, int dtype,
+                            float dropout_p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Row softmax for the dense attention variants (models/vit.py:96, attention.py:71,140,

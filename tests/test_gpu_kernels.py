@@ -269,13 +269,17 @@ def test_embed_prologue(K, B, N, D, dtype):
                                            (17, 5, 32, True), (65, 7, 64, False), (197, 7, 64, False),
                                            (197, 15, 16, False), (33, 9, 128, False), (64, 7, 64, False),
                                            (100, 3, 64, True)])
-@pytest.mark.parametrize("bwd_kernel", ["default", "tables", "valu"])
+@pytest.mark.parametrize("bwd_kernel", ["default", "tables", "valu", "lse"])
 def test_mhla_core_fwd_bwd_vs_window_gather(K, dtype, L, W, hd, masked, bwd_kernel, monkeypatch):
     """The attention core against a direct restatement of the reference's gather-based windows
     (duplicated pad indices take part in the softmax, models/mhla.py:117-154).  bf16, hd >= 32 has three
-    backward kernels: the default two-owner-pass MFMA kernel, the table formulation and the 8-lanes-per-row one."""
+    backward kernels without saved statistics: the default two-owner-pass MFMA kernel, the table formulation and the
+    8-lanes-per-row one; "lse" is the training path's pair (forward leaves lse, backward takes it and the output)."""
     from oracle import favit_oracle as O
-    if bwd_kernel != "default":
+    if bwd_kernel == "lse":
+        if not K.mhla_attn_lse_supported(L, hd, W, dtype):
+            pytest.skip("saved-statistics kernels: bf16, hd = 64, W <= 7 (11 with L > 16), L >= W + 1")
+    elif bwd_kernel != "default":
         if dtype != torch.bfloat16 or hd < 32:
             pytest.skip("kernel selection only exists for bf16, hd >= 32")
         monkeypatch.setenv("FAVIT_MHLA_BWD_TABLES" if bwd_kernel == "tables" else "FAVIT_MHLA_VALU", "1")   # read per call
@@ -289,8 +293,13 @@ def test_mhla_core_fwd_bwd_vs_window_gather(K, dtype, L, W, hd, masked, bwd_kern
         mask = (torch.rand(B, L, L, generator=g, device=DEV) > 0.4)
         mask |= torch.eye(L, dtype=torch.bool, device=DEV)
         mask = mask.to(torch.uint8).contiguous()
-    out = K.mhla_attn_fwd(qkv, B, L, H, hd, W, mask)
-    dqkv = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask)
+    lse = None
+    if bwd_kernel == "lse":
+        out, lse = K.mhla_attn_fwd(qkv, B, L, H, hd, W, mask, want_lse=True)
+        dqkv = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask, o=out, lse=lse)
+    else:
+        out = K.mhla_attn_fwd(qkv, B, L, H, hd, W, mask)
+        dqkv = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask)
     idx = torch.from_numpy(O.window_indices(L, W)).to(DEV)
     t = qkv.float().reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4).detach().clone().requires_grad_(True)
     q, k, v = t[0], t[1], t[2]
@@ -301,23 +310,34 @@ def test_mhla_core_fwd_bwd_vs_window_gather(K, dtype, L, W, hd, masked, bwd_kern
         s = s.masked_fill(wm == 0, float("-inf"))
     o = (torch.softmax(s, -1).unsqueeze(3) @ vw).squeeze(3).transpose(1, 2).reshape(B * L, D)
     assert rel_l2(out.float(), o) < _tol(dtype)
+    if lse is not None:
+        assert (lse - torch.logsumexp(s.detach(), -1)).abs().max().item() < 2e-3
     o.backward(dout.float())
     gref = t.grad.permute(1, 3, 0, 2, 4).reshape(B * L, 3 * D)
     assert rel_l2(dqkv.float(), gref) < (5e-5 if dtype == torch.float32 else 1.5e-2)
 
 
-@pytest.mark.parametrize("dtype,hd,L,tol", [(torch.float32, 16, 40, 1e-3), (torch.bfloat16, 64, 70, 3e-2),
-                                             (torch.bfloat16, 64, 5, 3e-2), (torch.bfloat16, 16, 40, 3e-2)])
-def test_mhla_core_dropout_consistency(K, dtype, hd, L, tol):
+@pytest.mark.parametrize("dtype,hd,L,tol,lse", [(torch.float32, 16, 40, 1e-3, False), (torch.bfloat16, 64, 70, 3e-2, False),
+                                                 (torch.bfloat16, 64, 5, 3e-2, False), (torch.bfloat16, 16, 40, 3e-2, False),
+                                                 (torch.bfloat16, 64, 70, 3e-2, True), (torch.bfloat16, 64, 197, 3e-2, True),
+                                                 (torch.bfloat16, 64, 17, 3e-2, True)])
+def test_mhla_core_dropout_consistency(K, dtype, hd, L, tol, lse):
     """Train-mode attention dropout: fwd (MFMA kernel for bf16 hd>=32) and bwd use the same
-    per-window-slot mask (out is linear in V, so <dout, out(V)> == <dV, V>)."""
+    per-window-slot mask (out is linear in V, so <dout, out(V)> == <dV, V>).  lse: the saved-statistics pair, whose
+    backward must also agree with the statistics-free kernel on all of dqkv (same masks, same seeds)."""
     B, H, W = 2, 2, 7
     D = H * hd
     g = torch.Generator(device=DEV).manual_seed(1000 + L * 7 + hd)
     qkv = _rand((B * L, 3 * D), dtype, g)
     dout = _rand((B * L, D), dtype, g)
-    out = K.mhla_attn_fwd(qkv, B, L, H, hd, W, None, 0.25, 77)
-    dqkv = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, None, 0.25, 77)
+    if lse:
+        out, st = K.mhla_attn_fwd(qkv, B, L, H, hd, W, None, 0.25, 77, want_lse=True)
+        assert st is not None
+        dqkv = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, None, 0.25, 77, o=out, lse=st)
+        assert rel_l2(dqkv.float(), K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, None, 0.25, 77).float()) < 1e-2
+    else:
+        out = K.mhla_attn_fwd(qkv, B, L, H, hd, W, None, 0.25, 77)
+        dqkv = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, None, 0.25, 77)
     lhs = (dout.float() * out.float()).sum().item()
     rhs = (dqkv[:, 2 * D:].float() * qkv[:, 2 * D:].float()).sum().item()
     # both sides are sums of random-sign terms: rounding noise AND a mask mismatch both scale with
@@ -820,6 +840,56 @@ def test_mhla_core_random_sweep(K, L, W, hd, B, H, masked, idx):
     o.backward(dout.float())
     gref = t.grad.permute(1, 3, 0, 2, 4).reshape(B * L, 3 * D)
     assert rel_l2(dqkv.float(), gref) < (5e-5 if dtype == torch.float32 else 1.5e-2)
+    if K.mhla_attn_lse_supported(L, hd, W, dtype):            # the training path's pair on the same case
+        out2, lse = K.mhla_attn_fwd(qkv, B, L, H, hd, W, mask, want_lse=True)
+        assert torch.equal(out2, out)
+        dq2 = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask, o=out2, lse=lse)
+        assert rel_l2(dq2.float(), gref) < 1.5e-2
+
+
+def _lse_cases():
+    rs = np.random.RandomState(11)
+    out = []
+    for i in range(36):
+        W = int(rs.choice([3, 5, 7, 9, 11]))
+        lo = max(W + 1, 17 if W > 7 else 0)
+        L = int(rs.choice([lo, lo + 1, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 66, 127, 128, 129, 197, 200, 577]))
+        out.append((max(L, lo), W, int(rs.randint(1, 3)), int(rs.randint(1, 4)), int(rs.randint(3)), i))
+    return out
+
+
+@pytest.mark.parametrize("L,W,B,H,mode,idx", _lse_cases())
+@pytest.mark.parametrize("waves", [0, 1, 4])
+def test_mhla_saved_statistics_backward_sweep(K, L, W, B, H, mode, idx, waves, monkeypatch):
+    """The saved-statistics pair (hd = 64, bf16) over sequence lengths around every tile / block edge, plain, masked
+    (mode 1) and with dropout (mode 2), at the default block size (3 tiles) and at 1 and 4 tiles per block: dqkv against the
+    statistics-free MFMA kernel on the same inputs (masks and dropout draws are identical by construction)."""
+    hd, dtype = 64, torch.bfloat16
+    if waves:
+        monkeypatch.setenv("FAVIT_MHLA_LSE_WAVES", str(waves))
+    assert K.mhla_attn_lse_supported(L, hd, W, dtype)
+    D = H * hd
+    g = torch.Generator(device=DEV).manual_seed(900 + idx)
+    qkv = _rand((B * L, 3 * D), dtype, g)
+    dout = _rand((B * L, D), dtype, g)
+    mask, p = None, 0.0
+    if mode == 1:
+        mask = (torch.rand(B, L, L, generator=g, device=DEV) > 0.4)
+        mask |= torch.eye(L, dtype=torch.bool, device=DEV)
+        mask = mask.to(torch.uint8).contiguous()
+    if mode == 2:
+        p = 0.2
+    out, lse = K.mhla_attn_fwd(qkv, B, L, H, hd, W, mask, p, 5 + idx, want_lse=True)
+    assert torch.equal(out, K.mhla_attn_fwd(qkv, B, L, H, hd, W, mask, p, 5 + idx))
+    got = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask, p, 5 + idx, o=out, lse=lse)
+    ref = K.mhla_attn_bwd(qkv, dout, B, L, H, hd, W, mask, p, 5 + idx)
+    assert torch.isfinite(got.float()).all()
+    for part, name in enumerate(("dq", "dk", "dv")):
+        a, b = got[:, part * D:(part + 1) * D].float(), ref[:, part * D:(part + 1) * D].float()
+        assert rel_l2(a, b) < 8e-3, name
+        # row by row: a wrong halo / wrap row would hide in the global norm
+        err = (a - b).reshape(B, L, D).norm(dim=-1) / (b.reshape(B, L, D).norm(dim=-1) + 1e-3 * b.norm() / (B * L) ** 0.5)
+        assert err.max().item() < 6e-2, (name, int(err.argmax()))
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
