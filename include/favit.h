@@ -225,7 +225,7 @@ int favit_mhla_attn_bwd(const void* qkv, const void* dout, void* dqkv, const uin
 /* The same attention core with the forward's softmax statistics handed to backward (ABI 6): `lse` fp32 [B, H, L] =
  * log sum_w exp(s_w) of every row's window (pad copies counted, mask applied), `o` = the forward's output.  With them
  * backward recomputes no softmax for rows outside a workgroup's block (P = exp(s - lse); delta = dO . O for the halo
- * rows: o is in bf16, so delta of those rows carries its rounding, ~2^-9 relative) -- the cfg2 launch takes @@ us
+ * rows: o is in bf16, so delta of those rows carries its rounding, ~2^-9 relative) -- the cfg2 launch takes 66 us
  * against 79.  favit_mhla_attn_lse_supported: 1 where both entry points run (bf16, hd = 64, odd W <= 7, or <= 11 with
  * L > 16; L >= W + 1), else the callers use the pair above. */
 int favit_mhla_attn_lse_supported(int32_t L, int32_t hd, int32_t W, int dtype);
