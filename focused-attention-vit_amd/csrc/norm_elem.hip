@@ -75,6 +75,65 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+// sum over the 32 lanes of an aligned half wave, in the VALU (DPP within rows of 16, v_permlane16_swap across them)
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v = dpp_sum8(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  return v + lane_xor16(v);
+}
+
+// Forward for D <= 512: TWO rows per wave, 32 lanes per row, NV float4 per lane.  At D = 384 every lane carries three
+// vectors (the one-row-per-wave kernel above leaves half of its second vector idle and has 1.5 KB in flight per wave),
+// and the two reductions cost five VALU exchanges each instead of six ds_bpermute round trips.
+template <typename OutT, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_half_kernel(const float* __restrict__ x, long ldx,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, OutT* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                          int D, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31;
+  const long row0 = ((long)blockIdx.x * 4 + wave) * 2 + (lane >> 5);
+  const bool live = row0 < rows;
+  const long row = live ? row0 : rows - 1;               // a dead half recomputes the last row and stores nothing
+  const float* xr = x + row * ldx;
+  const int nchunk = D >> 2;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i4 = l32 + 32 * c;
+    v[c] = (i4 < nchunk) ? *reinterpret_cast<const float4*>(xr + 4 * i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+  }
+  const float mu = half_wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i4 = l32 + 32 * c;
+    if (i4 < nchunk) {
+      const float a = v[c].x - mu, b = v[c].y - mu, cc = v[c].z - mu, d = v[c].w - mu;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rs = rsqrtf(half_wave_sum(q) / (float)D + eps);
+  if (!live) return;
+  if (l32 == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+  OutT* yr = y + row * (long)D;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i4 = l32 + 32 * c;
+    if (i4 < nchunk) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * i4);
+      const float4 b = *reinterpret_cast<const float4*>(beta + 4 * i4);
+      store4<OutT>(yr + 4 * i4, (v[c].x - mu) * rs * g.x + b.x, (v[c].y - mu) * rs * g.y + b.y,
+                   (v[c].z - mu) * rs * g.z + b.z, (v[c].w - mu) * rs * g.w + b.w);
+    }
+  }
+}
+
 template <typename DyT, typename LpT, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma,
@@ -498,6 +557,23 @@ extern "C" int favit_layernorm_fwd(const float* x, int64_t ldx, const float* gam
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || D <= 0) return FAVIT_ERR_INVALID;
   if ((D & 3) || (ldx & 3)) return FAVIT_ERR_ALIGN;
   hipStream_t st = as_stream(stream);
+  if (D <= 512 && getenv("FAVIT_LN_ONE_ROW") == nullptr) {          // two rows per wave
+    const dim3 grid2((unsigned)((rows + 7) / 8));
+#define LN_FWD2(NV)                                                                                                 \
+    do {                                                                                                            \
+      if (y_dtype == FAVIT_F32)                                                                                     \
+        hipLaunchKernelGGL((ln_fwd_half_kernel<float, NV>), grid2, dim3(256), 0, st, x, (long)ldx, gamma, beta,     \
+                           (float*)y, mean, rstd, (long)rows, D, eps);                                              \
+      else                                                                                                          \
+        hipLaunchKernelGGL((ln_fwd_half_kernel<bf16_t, NV>), grid2, dim3(256), 0, st, x, (long)ldx, gamma, beta,    \
+                           (bf16_t*)y, mean, rstd, (long)rows, D, eps);                                             \
+    } while (0)
+    const int nv2 = (D + 127) / 128;
+    if (nv2 <= 1) LN_FWD2(1); else if (nv2 == 2) LN_FWD2(2); else if (nv2 == 3) LN_FWD2(3); else LN_FWD2(4);
+#undef LN_FWD2
+    FAVIT_CHECK_LAUNCH();
+    return FAVIT_OK;
+  }
   const dim3 grid((unsigned)((rows + 3) / 4));
 #define LN_FWD(NV)                                                                                              \
   if (y_dtype == FAVIT_F32)                                                                                     \
