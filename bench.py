@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--backend", default=os.environ.get("FAVIT_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
     ap.add_argument("--no-gemm-trace", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="cfg2 / cfg4: replay the step from HIP graphs as well")
     ap.add_argument("--no-graph", action="store_true", help="cfg1 / cfg3: eager launches instead of the replayed HIP graph")
     ap.add_argument("--side-stream", action="store_true", help="run weight-gradient GEMMs on a second HIP stream")
     ap.add_argument("--dropout", type=float, default=0.0,
@@ -332,7 +333,7 @@ def main():
     else:
         groups = pkg.train.param_groups(model, lr=1e-4)
     opt = pkg.train.FusedAdamW(groups, lr=1e-4, weight_decay=0.05, bucket_mb=args.bucket_mb or None)
-    graphed = args.config in ("cfg1", "cfg3", "cfg5") and not args.no_graph
+    graphed = (args.config in ("cfg1", "cfg3", "cfg5") or args.graph) and not args.no_graph
     gstep = None
     if args.config == "cfg5":
         buckets = []

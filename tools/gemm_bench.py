@@ -9,7 +9,7 @@ if os.environ.get("FAVIT_GEMM_DBG"):      # work-skipping switches exist only in
     pkg._abi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_build", "libfavit_probe.so")
 K = pkg.kernels
 dev = "cuda"
-T, D = 256 * 197, 384
+T, D = int(os.environ.get("TOKENS", 256 * 197)), 384
 reps = int(os.environ.get("REPS", "20"))
 only = os.environ.get("ONLY")
 

@@ -7,6 +7,7 @@ The JSON is stamped with the fingerprint of csrc/ (the same one bench.py compute
 traffic figure as current while the kernel sources are the ones the passes were taken on.
 
 usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> <out.txt> [config] [dtype] [steps_profiled]
+(steps_profiled is only the fallback: the number of executed steps is read off the cross-entropy kernel's launch count)
 
 The JSON also lists EVERY kernel of the profiled run (bytes per launch, launches per step), from which bench.py
 computes `step_hbm`: the HBM bytes one training step moves, against the 8 TB/s peak."""
@@ -49,6 +50,12 @@ def main():
     dtype = sys.argv[6] if len(sys.argv) > 6 else "bf16"
     steps = int(sys.argv[7]) if len(sys.argv) > 7 else 3
     fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
+    # steps the profiled process actually EXECUTED: the cross-entropy kernel runs exactly once per step, also in the
+    # eager warm-up steps that train.GraphedStep runs before capturing (the graph-replayed configurations execute
+    # 3 + warmup + steps of them; counting `--steps 2 --warmup 1` as 3 doubled every per-step figure of cfg1/3/5)
+    ce = [v[1] for k, v in fe.items() if "cross_entropy_kernel" in k]
+    if ce:
+        steps = ce[0]
     rows = []
     for k in fe:
         n = fe[k][1]
