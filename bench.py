@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--backend", default=os.environ.get("FAVIT_DIST_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL; gloo only for rehearsing ranks on one GPU)")
     ap.add_argument("--no-gemm-trace", action="store_true")
+    ap.add_argument("--slic-noise", action="store_true", help="--slic on the step's N(0,1) noise images (worst case)")
     ap.add_argument("--graph", action="store_true", help="cfg2 / cfg4: replay the step from HIP graphs as well")
     ap.add_argument("--no-graph", action="store_true", help="cfg1 / cfg3: eager launches instead of the replayed HIP graph")
     ap.add_argument("--side-stream", action="store_true", help="run weight-gradient GEMMs on a second HIP stream")
@@ -418,18 +419,50 @@ def main():
     # (features + k-means + connectivity, ~10 launches) and copied into the buffer the replayed graph reads
     slic_inc = None
     if args.slic and args.config == "cfg3":
-        K.slic(images, n_segments=16, compactness=10.0)            # warm-up (lazy attributes, allocator)
+        # images with spatial correlation for the segmentation (a 14 x 14 random colour field upsampled bicubically and
+        # normalised like the loader's output): on N(0,1) pixel noise every image falls into ~2,000 connected
+        # components, the worst case of the connectivity stage, which no photograph produces (--slic-noise times that)
+        if args.slic_noise:
+            simg = images
+        else:
+            low = torch.rand(B, 3, 14, 14, device=dev, generator=g)
+            simg = ((torch.nn.functional.interpolate(low, size=(c["img"], c["img"]), mode="bicubic").clamp(0, 1) - 0.5) / 0.5).contiguous()
+        K.slic(simg, n_segments=16, compactness=10.0)              # warm-up (lazy attributes, allocator)
         sync()
         ts0 = time.perf_counter()
         for _ in range(args.steps):
-            segs.copy_(K.slic(images, n_segments=16, compactness=10.0))
+            segs.copy_(K.slic(simg, n_segments=16, compactness=10.0))
             step()
         sync()
         ts = time.perf_counter() - ts0
         slic_inc = {"images_per_sec": round(world * B * args.steps / ts, 2), "ms_per_step": round(1e3 * ts / args.steps, 3),
-                    "what": "device SLIC (compactness 10, 16 segments) of the batch + the step, every step; synthetic "
-                            "N(0,1) images, so the superpixel-token count is not 16 for every image: the replayed graph "
+                    "images": "N(0,1) pixel noise" if args.slic_noise else "smooth random colour fields, mean/std-normalised",
+                    "what": "device SLIC (compactness 10, 16 segments) of a batch + the step, every step; the "
+                            "superpixel-token count of synthetic images is not 16 for every image: the replayed graph "
                             "was captured for 16 tokens and the timing, not the loss, is what this line reports"}
+        # the same with the SLIC of batch i + 1 on a side stream under step i (what a prefetching loader does)
+        side = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        ready, used = torch.cuda.Event(), torch.cuda.Event()
+        nxt = K.slic(simg, n_segments=16, compactness=10.0)
+        ready.record(main)
+        sync()
+        ts0 = time.perf_counter()
+        for _ in range(args.steps):
+            main.wait_event(ready)
+            segs.copy_(nxt)
+            nxt.record_stream(main)
+            used.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(used)
+                nxt = K.slic(simg, n_segments=16, compactness=10.0)
+                ready.record(side)
+            step()
+        sync()
+        ts = time.perf_counter() - ts0
+        slic_inc["overlapped"] = {"images_per_sec": round(world * B * args.steps / ts, 2),
+                                  "ms_per_step": round(1e3 * ts / args.steps, 3),
+                                  "what": "SLIC of the next batch on a side stream while the step of this one runs"}
 
     # per-launch GEMM timing: two extra EAGER steps after the timed region (events cannot be captured in a graph).
     # Every rank runs them (the all-reduce inside opt.step() is collective); only rank 0 records events.
