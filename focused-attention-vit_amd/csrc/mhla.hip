@@ -2206,17 +2206,20 @@ extern "C" int favit_mhla_fold_bwd_multi(int32_t n, const float* const* dweff, c
   if (n <= 0 || n > FOLD_BWD_MAX || !dweff || !dbeff || !wqkv || !bqkv || !wl || !dwqkv || !dbqkv || !dwl || !dbl ||
       D <= 0 || H <= 0 || D % H)
     return FAVIT_ERR_INVALID;
+  // dwqkv[i] == dbqkv[i] == NULL for EVERY layer: the qkv projection is frozen (fine-tuning), only the latent_proj
+  // gradients are produced and the workgroups of the qkv part are not launched
+  const bool lat_only = dwqkv[0] == nullptr;
   FoldBwdBatch fb;
   for (int i = 0; i < n; ++i) {
-    if (!dweff[i] || !dbeff[i] || !wqkv[i] || !bqkv[i] || !wl[i] || !dwqkv[i] || !dbqkv[i] || !dwl[i] || !dbl[i])
-      return FAVIT_ERR_INVALID;
+    if (!dweff[i] || !dbeff[i] || !wqkv[i] || !bqkv[i] || !wl[i] || !dwl[i] || !dbl[i]) return FAVIT_ERR_INVALID;
+    if (lat_only ? (dwqkv[i] || dbqkv[i]) : (!dwqkv[i] || !dbqkv[i])) return FAVIT_ERR_INVALID;
     fb.dweff[i] = dweff[i]; fb.dbeff[i] = dbeff[i]; fb.wqkv[i] = wqkv[i]; fb.bqkv[i] = bqkv[i]; fb.wl[i] = wl[i];
     fb.dwqkv[i] = dwqkv[i]; fb.dbqkv[i] = dbqkv[i]; fb.dwl[i] = dwl[i]; fb.dbl[i] = dbl[i];
   }
   const int hd = D / H;
   const int gwx = (D + 1 + FOLD_TC - 1) / FOLD_TC, gwy = 2 * H + (D + hd - 1) / hd;      // fold_w grid
   const int glx = 2 * H, gly = (D + 64) / 64;                                             // fold_bwd_l grid
-  const int nw = gwx * gwy;
+  const int nw = lat_only ? 0 : gwx * gwy;
   const dim3 grid((unsigned)(nw + glx * gly), (unsigned)n);
   hipStream_t st = as_stream(stream);
   switch (hd) {

@@ -423,7 +423,7 @@ def flush_wgrads() -> None:
     _WG["list"] = [] if lst is not None else None
     probs = [(dy, a, dw, db, acc) for dy, a, dw, db, acc, _ in lst]
     with _side_stream(*[t for pr in probs for t in pr[:4]]):
-        if len(probs) < 2 or not K.gemm_grouped_tn(probs):
+        if not K.gemm_grouped_tn(probs):       # (one problem too: fine-tuning with frozen layers leaves only dWeff)
             for dy, a, dw, db, acc in probs:
                 K.gemm(dy, a, dw, dy.shape[1], a.shape[1], dy.shape[0], dy.stride(0), a.stride(0), dw.stride(0),
                        a_kmajor=False, b_kmajor=False, a_rowsum=db, accumulate=acc)
@@ -467,8 +467,8 @@ def flush_deferred(force: bool = True) -> None:
             _ready(*e[3])
     by_h = {}
     for e in fold:
-        by_h.setdefault((e[6], tuple(e[2].shape)), []).append(e)
-    for (H, _), es in by_h.items():
+        by_h.setdefault((e[6], tuple(e[2].shape), e[5][0] is None), []).append(e)
+    for (H, _, _), es in by_h.items():
         K.mhla_fold_bwd_multi([e[:6] for e in es], H)
         for e in es:
             _ready(*e[7])
@@ -642,6 +642,12 @@ class MHLAChain:
         tg = [_gt(p) for p in (wqkv, bqkv, wl, bl)]
         if all(t is not None for t in tg) and _DEFER["on"]:
             _DEFER["fold"].append((dweff, dbeff, wqkv.detach(), bqkv.detach(), wl.detach(), tg, H, (wqkv, bqkv, wl, bl)))
+            return dxn, [None, None, None, None, dwp, dbp]
+        if (_DEFER["on"] and not wqkv.requires_grad and not bqkv.requires_grad and tg[2] is not None and tg[3] is not None):
+            # frozen qkv projection, trainable latent_proj (experiments/sppp_mhla_pretrained.py:236-247): the batched
+            # launch with its qkv half switched off, straight into the latent_proj gradient buffers
+            _DEFER["fold"].append((dweff, dbeff, wqkv.detach(), bqkv.detach(), wl.detach(), [None, None, tg[2], tg[3]], H,
+                                   (wl, bl)))
             return dxn, [None, None, None, None, dwp, dbp]
         if all(t is not None for t in tg):
             with _side_stream(dweff, dbeff):
@@ -972,6 +978,8 @@ class EncoderOp:
         def ln_bwd(dxn, xin, gam, bet, mu, rs, dres, pd):
             """LayerNorm backward of the stream; the dgamma / dbeta fold joins the deferred batch when the parameters own
             gradient buffers (the fused-optimizer flow)."""
+            if not gam.requires_grad and not bet.requires_grad:      # frozen layer: no dgamma / dbeta fold at all
+                return K.layernorm_bwd(dxn, xin, D, gam, mu, rs, M, D, dres=dres, want_lp=True, lp_drop=pd, frozen=True)
             tg_, tb_ = _gt(gam), _gt(bet)
             lst = _DEFER["ln"] if (_DEFER["on"] and tg_ is not None and tb_ is not None) else None
             n0 = len(lst) if lst is not None else 0

@@ -120,6 +120,11 @@ def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias
 
 
 _GROUPED_WS = {}          # device index -> workspace tensor of the slab-mode split-K reduction
+# Workspaces that were outgrown stay alive: a captured HIP graph holds their ADDRESS (train.GraphedStep: one graph per
+# token-count bucket, the second bucket can need a larger workspace than the first), and torch.cuda.graph() empties the
+# allocator cache when the next capture begins -- a freed workspace is then unmapped under the first graph's replays
+# (memory access fault; found with the two-bucket cfg5 bench once its one-problem launches took the slab path).
+_GROUPED_WS_RETIRED = []
 
 
 def gemm_grouped_tn(problems, use_workspace: bool = True) -> bool:
@@ -155,6 +160,8 @@ def gemm_grouped_tn(problems, use_workspace: bool = True) -> bool:
         dev = problems[0][0].device
         ws = _GROUPED_WS.get(dev.index)
         if ws is None or ws.numel() < need:
+            if ws is not None:
+                _GROUPED_WS_RETIRED.append(ws)
             ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
             _GROUPED_WS[dev.index] = ws
         rc = _abi.lib().favit_gemm_grouped_tn_ws(arr, n, _p(ws), ws.numel(), _st())
@@ -248,13 +255,14 @@ def layernorm_fwd(x, ldx, gamma, beta, rows, D, out_dtype, eps=1e-5):
 
 
 def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None, lddx=None, want_lp=False,
-                  dg_out=None, db_out=None, lp_drop=(0.0, 0), defer=None):
+                  dg_out=None, db_out=None, lp_drop=(0.0, 0), defer=None, frozen=False):
     """Returns dx (fp32, row stride lddx), dx_lp (dy.dtype copy or None), dgamma, dbeta.
     dg_out / db_out: optional fp32 [D] gradient buffers the affine gradients are ACCUMULATED into
     (then None is returned in their place).  lp_drop = (p, seed): dx_lp carries that dropout mask (the branch it
     feeds had its output dropped in forward), saving a separate masking pass.
     defer (a list, with dg_out / db_out): the fold of the partial sums into dg_out / db_out is NOT launched; the
-    entry (part, dg_out, db_out) is appended and the caller folds several of them in one launch (reduce_rows_multi)."""
+    entry (part, dg_out, db_out) is appended and the caller folds several of them in one launch (reduce_rows_multi).
+    frozen: gamma and beta take no gradient (fine-tuning with frozen layers): no fold launch at all, (.., None, None)."""
     require_gpu(dy, x)
     dev = x.device
     if dx is None:
@@ -264,7 +272,9 @@ def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None,
     nparts = int(min(2048, (rows + 3) // 4))
     part = torch.empty((2, nparts, D), dtype=torch.float32, device=dev)
     acc = dg_out is not None and db_out is not None
-    if acc and defer is not None:
+    if frozen:
+        acc, dg, db = True, None, None
+    elif acc and defer is not None:
         defer.append((part, dg_out, db_out))
         dg = db = None
     elif acc:
@@ -362,8 +372,8 @@ def mhla_fold_bwd_multi(entries, H):
         cols = []
         for j in range(5):
             cols.append(arr(*[e[j].data_ptr() for e in chunk]))
-        for j in range(4):
-            cols.append(arr(*[e[5][j].data_ptr() for e in chunk]))
+        for j in range(4):     # (dwqkv, dbqkv may be None for every layer: frozen qkv projection, latent_proj gradients only)
+            cols.append(arr(*[(e[5][j].data_ptr() if e[5][j] is not None else None) for e in chunk]))
         for e in chunk:
             require_gpu(*e[:5], *e[5])
         _abi.check(_abi.lib().favit_mhla_fold_bwd_multi(n, *cols, D, H, _st()), "favit_mhla_fold_bwd_multi")

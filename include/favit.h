@@ -205,7 +205,8 @@ int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const float* wqk
                         const float* wl, float* dwqkv, float* dbqkv, float* dwl, float* dbl, int32_t D, int32_t H,
                         int32_t accumulate, void* stream);
 /* The backward fold of n (<= 16) layers in ONE launch, always ACCUMULATING into the gradient buffers (HOST arrays of n
- * device pointers, as favit_mhla_fold_fwd_multi). */
+ * device pointers, as favit_mhla_fold_fwd_multi).  dwqkv[i] = dbqkv[i] = NULL for every layer: frozen qkv projection
+ * (the fine-tuning setup of experiments/sppp_mhla_pretrained.py:236-247), only dwl / dbl are produced. */
 int favit_mhla_fold_bwd_multi(int32_t n, const float* const* dweff, const float* const* dbeff, const float* const* wqkv,
                               const float* const* bqkv, const float* const* wl, float* const* dwqkv,
                               float* const* dbqkv, float* const* dwl, float* const* dbl, int32_t D, int32_t H,

@@ -97,6 +97,46 @@ def test_gemm_grouped_tn_short_token_counts(K):
         assert rel_l2(dw, ref_w) < 2e-5 and rel_l2(db, ref_b) < 2e-5
 
 
+def test_gemm_grouped_tn_single_problem_short_token_counts(K):
+    """One problem per launch (fine-tuning with frozen layers leaves only the folded-qkv weight gradient of a block) at
+    the two token counts of the cfg5 buckets: 8 and 32 K-splits."""
+    for T in (128 * 17, 128 * 16):
+        gen = torch.Generator(device=DEV).manual_seed(T)
+        probs, refs = _block_problems(T, gen, False)
+        assert K.gemm_grouped_tn(probs[3:])
+        (dy, x, dw, db, _), (ref_w, ref_b) = probs[3], refs[3]
+        assert rel_l2(dw, ref_w) < 2e-5 and rel_l2(db, ref_b) < 2e-5
+
+
+def test_gemm_grouped_tn_workspace_outgrown_under_a_captured_graph(K):
+    """A captured graph holds the ADDRESS of the slab workspace.  When a later launch needs a larger one, the old
+    buffer must stay alive: torch.cuda.graph() empties the allocator cache at the next capture, and a freed workspace
+    would be unmapped under the first graph's replays (the two-bucket cfg5 bench faulted exactly like this)."""
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    small, refs = _block_problems(512, gen, False, D=192)
+    K._GROUPED_WS.clear()                                  # the graph's launch allocates the workspace it captures
+    assert K.gemm_grouped_tn(small)                        # warm-up outside the capture (allocates)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        assert K.gemm_grouped_tn(small)
+    first = K._GROUPED_WS[torch.cuda.current_device()]
+    big, _ = _block_problems(2048 + 32, gen, False)        # D = 384, more tokens: a larger workspace
+    assert K.gemm_grouped_tn(big)
+    assert K._GROUPED_WS[torch.cuda.current_device()] is not first and any(w is first for w in K._GROUPED_WS_RETIRED)
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):                             # (empties the allocator cache on entry)
+        assert K.gemm_grouped_tn(big)
+    for p in small:
+        p[2].fill_(float("nan"))
+        p[3].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for (dy, x, dw, db, _), (ref_w, ref_b) in zip(small, refs):
+        assert rel_l2(dw, ref_w) < 2e-5 and rel_l2(db, ref_b) < 2e-5
+
+
 def test_gemm_grouped_tn_declines_what_it_cannot_group(K):
     gen = torch.Generator(device=DEV).manual_seed(3)
     T = 197 * 2                                  # not a multiple of 32: callers fall back to single launches
