@@ -1788,8 +1788,11 @@ __global__ __launch_bounds__(256) void fold_w_kernel(const float* __restrict__ w
 }
 
 // dWl[i][j] += sum_c dWeff_z[i][c] Wqkv_z[j][c] + dbeff_z[i] bqkv_z[j];  dbl[i] += dbeff_z[i].
-// grid (2H): one workgroup per (s,h) block z walks the D+1 columns in tiles of 64 (register-blocked
-// [HD x HD] accumulator) and adds its partial with fp32 atomics (2H-way contention only).
+// grid (2H, FOLD_L_SPLIT): a workgroup takes one (s,h) block z and walks HALF of the D+1 columns in tiles of 64 with a
+// register-blocked [HD x HD] accumulator, then adds its partial with fp32 atomics -- 2 * 2H partials per layer land on
+// the same HD x HD words.  (One tile per workgroup, as before round 3, made that 2H * (D/64 + 1): 312-way contention
+// at ViT-Base, 349 us for the twelve layers of a cfg4 step.)
+constexpr int FOLD_L_SPLIT = 4;
 template <int HD>
 __device__ __forceinline__ void fold_bwd_l_body(const float* __restrict__ dweff, const float* __restrict__ dbeff,
                                                 const float* __restrict__ wqkv, const float* __restrict__ bqkv,
@@ -1802,39 +1805,47 @@ __device__ __forceinline__ void fold_bwd_l_body(const float* __restrict__ dweff,
   const int tc = threadIdx.x & 63, tg = threadIdx.x >> 6;
   const long base = (long)D + (long)bx * HD;
   const int i0 = TR * (threadIdx.x >> 4), j0 = TR * (threadIdx.x & 15);
-  const int c = by * 64 + tc;                  // column D = bias column
-  float va[HD / 4], vb[HD / 4];
-#pragma unroll
-  for (int q = 0; q < HD / 4; ++q) {
-    const int r = tg + 4 * q;
-    va[q] = (c < D) ? dweff[(base + r) * D + c] : (c == D ? dbeff[base + r] : 0.f);
-    vb[q] = (c < D) ? wqkv[(base + r) * D + c] : (c == D ? bqkv[base + r] : 0.f);
-  }
-#pragma unroll
-  for (int q = 0; q < HD / 4; ++q) {
-    sa[tc * LDT + tg + 4 * q] = va[q];
-    sb[tc * LDT + tg + 4 * q] = vb[q];
-  }
-  __syncthreads();
+  const int ntile = (D + 64) / 64;                     // tiles of 64 columns over D + 1 (column D = the bias)
+  const int per = (ntile + FOLD_L_SPLIT - 1) / FOLD_L_SPLIT;
+  const int t_lo = by * per, t_hi = min(ntile, t_lo + per);
   float acc[TR][TR];
 #pragma unroll
   for (int i = 0; i < TR; ++i)
 #pragma unroll
     for (int j = 0; j < TR; ++j) acc[i][j] = 0.f;
-#pragma unroll 4
-  for (int k = 0; k < 64; ++k) {
-    float a[TR], bb[TR];
+  for (int t = t_lo; t < t_hi; ++t) {
+    const int c = t * 64 + tc;
+    float va[HD / 4], vb[HD / 4];
 #pragma unroll
-    for (int i = 0; i < TR; ++i) { a[i] = sa[k * LDT + i0 + i]; bb[i] = sb[k * LDT + j0 + i]; }
+    for (int q = 0; q < HD / 4; ++q) {
+      const int r = tg + 4 * q;
+      va[q] = (c < D) ? dweff[(base + r) * D + c] : (c == D ? dbeff[base + r] : 0.f);
+      vb[q] = (c < D) ? wqkv[(base + r) * D + c] : (c == D ? bqkv[base + r] : 0.f);
+    }
+    if (t > t_lo) __syncthreads();                     // the previous tile has been consumed
+#pragma unroll
+    for (int q = 0; q < HD / 4; ++q) {
+      sa[tc * LDT + tg + 4 * q] = va[q];
+      sb[tc * LDT + tg + 4 * q] = vb[q];
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 64; ++k) {
+      float a[TR], bb[TR];
+#pragma unroll
+      for (int i = 0; i < TR; ++i) { a[i] = sa[k * LDT + i0 + i]; bb[i] = sb[k * LDT + j0 + i]; }
+#pragma unroll
+      for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TR; ++j) acc[i][j] = fmaf(a[i], bb[j], acc[i][j]);
+    }
+  }
+  if (t_lo < t_hi) {
 #pragma unroll
     for (int i = 0; i < TR; ++i)
 #pragma unroll
-      for (int j = 0; j < TR; ++j) acc[i][j] = fmaf(a[i], bb[j], acc[i][j]);
+      for (int j = 0; j < TR; ++j) atomicAdd(dwl + (long)(i0 + i) * HD + j0 + j, acc[i][j]);
   }
-#pragma unroll
-  for (int i = 0; i < TR; ++i)
-#pragma unroll
-    for (int j = 0; j < TR; ++j) atomicAdd(dwl + (long)(i0 + i) * HD + j0 + j, acc[i][j]);
   if (by == 0 && threadIdx.x < HD) atomicAdd(dbl + threadIdx.x, dbeff[base + threadIdx.x]);
 }
 
@@ -2186,7 +2197,7 @@ extern "C" int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const
     (void)hipMemsetAsync(dbl, 0, sizeof(float) * hd, st);
   }
   const int gwx = (D + 1 + FOLD_TC - 1) / FOLD_TC, gwy = 2 * H + (D + hd - 1) / hd;      // fold_w grid
-  const int glx = 2 * H, gly = (D + 64) / 64;                                             // fold_bwd_l grid
+  const int glx = 2 * H, gly = FOLD_L_SPLIT;                                             // fold_bwd_l grid
   const int nw = gwx * gwy;
   const dim3 grid((unsigned)(nw + glx * gly));
   switch (hd) {
@@ -2218,7 +2229,7 @@ extern "C" int favit_mhla_fold_bwd_multi(int32_t n, const float* const* dweff, c
   }
   const int hd = D / H;
   const int gwx = (D + 1 + FOLD_TC - 1) / FOLD_TC, gwy = 2 * H + (D + hd - 1) / hd;      // fold_w grid
-  const int glx = 2 * H, gly = (D + 64) / 64;                                             // fold_bwd_l grid
+  const int glx = 2 * H, gly = FOLD_L_SPLIT;                                             // fold_bwd_l grid
   const int nw = lat_only ? 0 : gwx * gwy;
   const dim3 grid((unsigned)(nw + glx * gly), (unsigned)n);
   hipStream_t st = as_stream(stream);
