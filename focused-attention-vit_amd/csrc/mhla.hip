@@ -1318,11 +1318,12 @@ __global__ __launch_bounds__(256) void mhla_bwd_mfma2_kernel(AttnArgs a) {
 // 64-term dot product for the <= 4h + 1 halo / wrap rows of a block (owned rows keep the exact fp32 sum of pass 1).
 //   * pass 1 runs over the OWNED 16-row tiles only (the table-free kernel above also ran the halo tiles: 15-17 query
 //     tiles per (batch, head) at L = 197 against 13 here), rows [r0 - h, r1 + h) are staged once for all four images
-//     (K~/V~ needed [r0 - 2h, r1 + 2h) before) and blocks are whole tiles: rb = 64 rows, one wave per tile in both
-//     passes;
+//     (K~/V~ needed [r0 - 2h, r1 + 2h) before) and blocks are whole tiles: rb = 48 rows = three waves, one wave per
+//     tile in both passes (the host picks the tile count per block, attn_entry);
 //   * 128-byte LDS rows with the 16-byte chunks XOR-swizzled by the row index instead of 144-byte padded rows:
-//     (rb + 2h + 2) K~/V~ rows and (rb + 4h + 1) Q / dO rows = 38.8 KiB at W = 7 -> four workgroups per CU.
-// 271 MB of algorithmic traffic + 6 % for the halo rows; see DESIGN.md for the measured split.
+//     (rb + 2h + 2) K~/V~ rows and (rb + 4h + 1) Q / dO rows + statistics + the dump area = 31.5 KiB at W = 7, three
+//     tiles -> five workgroups per CU.
+// 272 MB of algorithmic traffic; 314 MB measured (halo rows, lse, the O rows of the halo); DESIGN.md has the split.
 // ---------------------------------------------------------------------------------
 // PairStager for a run-time thread count and swizzled 128-byte rows: load() issues every request, store() writes LDS.
 //  * addresses = a workgroup-uniform base + a 32-bit byte offset per lane (the SGPR-base form of global_load: one
