@@ -985,6 +985,13 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
   db = P4_A_BYTES + wave * 1024;
   const long a_step = AK ? 64 : (long)P4_BK * p.lda * 2;      // bytes per stage
   const long b_step = BKM ? 64 : (long)P4_BK * p.ldb * 2;
+#ifdef FAVIT_PROBE
+  // dbg 0x2000 (timing only, wrong results): the B operand is NOT streamed -- what a launch would take if a weight
+  // slice stayed in LDS and only A were fetched (tools/gemm_bench.py)
+  const bool no_b = (p.dbg & 0x2000) != 0;
+#else
+  constexpr bool no_b = false;
+#endif
   auto issue = [&](int buf) {
     char* st = smem + buf * P4_STAGE;
 #pragma unroll
@@ -992,16 +999,20 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
       __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + da[j]), 16, 0, 0);
       sa[j] += a_step;
     }
-    __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + db), 16, 0, 0);
-    sb += b_step;
+    if (!no_b) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + db), 16, 0, 0);
+      sb += b_step;
+    }
   };
 
   if (nk > 0) issue(0);
   if (nk > 1) issue(1);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kt + 1 < nk) {
+      if (no_b) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);
     const char* st = smem + cur * P4_STAGE;
