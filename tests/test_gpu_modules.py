@@ -361,6 +361,44 @@ def test_frozen_layers_flow_of_the_experiments(favit):
     assert sorted(len(g["params"]) for g in groups) == [2, 4]
 
 
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-4), ("bf16", 4e-2)])
+def test_frozen_layers_with_the_fused_optimizer(favit, mode, tol):
+    """The fine-tuning flow as the benchmark's cfg5 runs it: frozen blocks, trainable head / latent_proj, gradients
+    written straight into the fused optimizer's flat buffers.  This is the path on which the batched fold backward runs
+    with its qkv half switched off, frozen LayerNorms skip their parameter-gradient fold and a block's only
+    weight-gradient problem (the folded qkv weight) takes the slab launch -- gradients against the oracle."""
+    from oracle import favit_oracle as O
+    favit.set_compute_dtype(mode)
+    try:
+        torch.manual_seed(9)
+        m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=128, depth=3,
+                                                        num_heads=2, use_mhla=True).to(DEV).train()
+        for n, p in m.named_parameters():
+            p.requires_grad = ("head" in n) or ("latent_proj" in n)
+        opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=1e-3, head_lr=1e-2), lr=1e-3, distributed=False)
+        x = torch.randn(32, 3, 32, 32, device=DEV)         # 32 x 65 = 2,080 tokens: a multiple of 32 -> the slab launch
+        y = torch.randint(0, 10, (32,), device=DEV)
+        sd = {k: v.detach().cpu().clone().requires_grad_(("head" in k) or ("latent_proj" in k)) for k, v in m.state_dict().items()}
+        lo = O.cross_entropy(O.vit_mhla_forward(x.cpu(), sd, 4, 2, 7, True), y.cpu())
+        lo.backward()
+        for _ in range(2):                                 # twice: zero_grad must reset what the first pass accumulated
+            opt.zero_grad()
+            loss = favit.train.cross_entropy(m(x), y)
+            loss.backward()
+        assert abs(loss.item() - lo.item()) < tol * max(1.0, abs(lo.item()))
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                gbuf = favit.functional._gt(p)
+                assert gbuf is not None, n
+                assert rel_l2(gbuf.cpu(), sd[n].grad) < (1e-4 if mode == "fp32" else 5e-2), n
+            else:
+                assert p.grad is None and favit.functional._gt(p) is None, n
+    finally:
+        favit.set_compute_dtype("fp32")
+        favit.functional.clear_lp_mirrors()
+        favit.functional.set_grad_ready_hook(None)
+
+
 @pytest.mark.parametrize("mode,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
 def test_torch_optim_adamw_training_steps(favit, mode, tol):
     """The reference's own loop (torch.optim.AdamW, experiments/mhla_pretrained.py:308-372) over three
