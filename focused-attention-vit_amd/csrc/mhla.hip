@@ -249,6 +249,22 @@ struct PairStager {
       }
     }
   }
+  // Branch-free variant: chunks past the end go to a 1-KiB dump area (one 16-byte slot per lane).  With the predicated
+  // store() the compiler sinks every load into its store's block and the chunks of a thread make their round trips one
+  // after the other (see mhla_bwd_lse_kernel); this keeps all of them in flight.
+  __device__ __forceinline__ void store_dump(char* ldsA, char* ldsB, char* dump, int nrows, int hd, int rs, int tid) const {
+    const int cpr = hd * (int)sizeof(T) / 16;
+    const int total = nrows * cpr;
+    char* mine = dump + (tid & 63) * 16;
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int c = tid + 256 * it;
+      const int s = c / cpr, ch = c - s * cpr;
+      const bool ok = c < total;
+      *reinterpret_cast<uint4*>(ok ? ldsA + s * rs + ch * 16 : mine) = ra[it];
+      *reinterpret_cast<uint4*>(ok ? ldsB + s * rs + ch * 16 : mine) = rb[it];
+    }
+  }
 };
 
 struct AttnArgs {
@@ -594,12 +610,19 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
   im.init(r0 - h, r1 + h, 1, L);
   char* ldsK = smem;
   char* ldsV = smem + im.n_rows * RS;
+  bf16x8 qfr[HD / 32];
   {
     constexpr int NCH = (80 * (HD * 2 / 16) + 255) / 256;
     PairStager<bf16_t, NCH> skv;
     auto rowf = [&](int s) { return im.row_of_slot(s); };
     skv.load(im.n_rows, qkv, ld, D + head * HD, qkv, ld, 2 * D + head * HD, tok0, HD, tid, rowf);
-    skv.store(ldsK, ldsV, im.n_rows, HD, RS, tid);
+    // this lane's query fragments are requested together with the K~ / V~ rows (they used to be loaded after the
+    // barrier: one more exposed round trip per workgroup)
+    const int tq = min(r0 + 16 * wave + qi, L - 1);
+    const bf16_t* qrow0 = qkv + (tok0 + tq) * ld + head * HD;
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) qfr[ks] = *reinterpret_cast<const bf16x8*>(qrow0 + 32 * ks + 8 * g);
+    skv.store_dump(ldsK, ldsV, ldsV + im.n_rows * RS, im.n_rows, HD, RS, tid);
   }
   __syncthreads();
 
@@ -614,12 +637,11 @@ __global__ __launch_bounds__(256) void mhla_fwd_mfma_kernel(AttnArgs a) {
   si.init(min(i, L - 1), L, W, h);
 
   // ---- S = K_slots . Q^T ----
-  const bf16_t* qrow = qkv + (tok0 + si.i) * ld + head * HD;
   f32x4 S[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
   const int krow0 = im.slot(slot_key(qi, t0, h, L)), krow1 = im.slot(slot_key(16 + qi, t0, h, L));
 #pragma unroll
   for (int ks = 0; ks < HD / 32; ++ks) {
-    const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qrow + 32 * ks + 8 * g);
+    const bf16x8 qf = qfr[ks];
     const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(ldsK + krow0 * RS + (32 * ks + 8 * g) * 2);
     const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(ldsK + krow1 * RS + (32 * ks + 8 * g) * 2);
     S[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf, S[0], 0, 0, 0);
@@ -2022,7 +2044,7 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
   hipStream_t st = as_stream(stream);
   if (!bwd && dtype == FAVIT_BF16 && (hd == 32 || hd == 64 || hd == 128) && getenv("FAVIT_MHLA_VALU") == nullptr) {
     const int h = W / 2;
-    const size_t lds = (size_t)2 * (64 + 2 * h + 2) * (hd * 2 + 16);
+    const size_t lds = (size_t)2 * (64 + 2 * h + 2) * (hd * 2 + 16) + 1024;      // K~ / V~ images + the staging dump area
     dim3 grid((L + 63) / 64, H, B);
     const bool plain = (mask == nullptr) && (a.thresh == 0);
     if (hd == 32) { if (plain) hipLaunchKernelGGL((mhla_fwd_mfma_kernel<32, true>), grid, dim3(256), lds, st, a); else hipLaunchKernelGGL((mhla_fwd_mfma_kernel<32, false>), grid, dim3(256), lds, st, a); }
