@@ -134,10 +134,10 @@ __device__ __forceinline__ void acc_transposed(f32x4 (&acc)[NDT], const char* ti
 // rows [s0, s0 + 32) x hd of a streamed matrix -> LDS (zero beyond Ls rows and in the padded columns)
 template <typename T>
 __device__ __forceinline__ void stage_tile(char* tile, int rs, const T* base, long ld, int s0, int Ls, int hd,
-                                           int hd_pad, int tid, int nrows) {
+                                           int hd_pad, int tid, int nrows, int nthr) {
   constexpr int EPC = 16 / (int)sizeof(T);            // elements per 16-byte chunk
   const int cpr = hd_pad / EPC;
-  for (int c = tid; c < nrows * cpr; c += 256) {
+  for (int c = tid; c < nrows * cpr; c += nthr) {
     const int r = c / cpr, ch = c - r * cpr;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (s0 + r < Ls && (ch + 1) * EPC <= hd) v = *reinterpret_cast<const uint4*>(base + (long)(s0 + r) * ld + ch * EPC);
@@ -150,11 +150,11 @@ __device__ __forceinline__ void stage_tile(char* tile, int rs, const T* base, lo
 constexpr int SDPA_PF = 2;
 template <typename T>
 __device__ __forceinline__ void tile_gload(uint4 (&r)[SDPA_PF], const T* base, long ld, int s0, int Ls, int hd, int cpr,
-                                           int nchunks, int tid) {
+                                           int nchunks, int tid, int nthr) {
   constexpr int EPC = 16 / (int)sizeof(T);
 #pragma unroll
   for (int j = 0; j < SDPA_PF; ++j) {
-    const int c = tid + 256 * j;
+    const int c = tid + nthr * j;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (c < nchunks) {
       const int row = c / cpr, ch = c - row * cpr;
@@ -163,10 +163,11 @@ __device__ __forceinline__ void tile_gload(uint4 (&r)[SDPA_PF], const T* base, l
     r[j] = v;
   }
 }
-__device__ __forceinline__ void tile_lstore(char* tile, int rs, const uint4 (&r)[SDPA_PF], int cpr, int nchunks, int tid) {
+__device__ __forceinline__ void tile_lstore(char* tile, int rs, const uint4 (&r)[SDPA_PF], int cpr, int nchunks, int tid,
+                                            int nthr) {
 #pragma unroll
   for (int j = 0; j < SDPA_PF; ++j) {
-    const int c = tid + 256 * j;
+    const int c = tid + nthr * j;
     if (c < nchunks) {
       const int row = c / cpr, ch = c - row * cpr;
       *reinterpret_cast<uint4*>(tile + row * rs + ch * 16) = r[j];
@@ -175,11 +176,11 @@ __device__ __forceinline__ void tile_lstore(char* tile, int rs, const uint4 (&r)
 }
 
 template <typename T, int NDT, int MODE>
-__global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
+__global__ __launch_bounds__(320) void sdpa_kernel(SdpaArgs a) {      // 4 or 5 waves: 64 or 80 owner rows per workgroup
   if (a.thresh) a.seed = favit_eff_seed(a.seed, a.epoch);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef Mma<T> M;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
   const int z = blockIdx.y, b = z / a.H, h = z % a.H;
   const int d0 = blockIdx.z * (16 * NDT);
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
   const T* strA = MODE == 2 ? Q : Kp;   const long strA_ld = MODE == 2 ? a.vq.ld : a.vk.ld;
   const T* strB = MODE == 2 ? dO : V;   const long strB_ld = MODE == 2 ? a.vdo.ld : a.vv.ld;
 
-  const int on = blockIdx.x * 64 + wave * 16 + n;      // this lane's owner row
+  const int on = blockIdx.x * (nthr >> 2) + wave * 16 + n;      // this lane's owner row (16 rows per wave)
   const int onc = min(on, Lo - 1);
   const T* oa_row = ownA + (long)onc * ownA_ld;
   const T* ob_row = MODE ? ownB + (long)onc * ownB_ld : nullptr;
@@ -235,21 +236,21 @@ __global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
   // streamed rows of the NEXT block travel in registers while this block is consumed (small tiles only)
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cpr = hd_pad / EPC, nchunks = SB * cpr;
-  const bool pf = hoisted && nchunks <= SDPA_PF * 256 && !a.mask;
+  const bool pf = hoisted && nchunks <= SDPA_PF * nthr && !a.mask;
   uint4 pra[SDPA_PF], prb[SDPA_PF];
   if (pf) {
-    tile_gload<T>(pra, strA, strA_ld, 0, Ls, hd, cpr, nchunks, tid);
-    tile_gload<T>(prb, strB, strB_ld, 0, Ls, hd, cpr, nchunks, tid);
+    tile_gload<T>(pra, strA, strA_ld, 0, Ls, hd, cpr, nchunks, tid, nthr);
+    tile_gload<T>(prb, strB, strB_ld, 0, Ls, hd, cpr, nchunks, tid, nthr);
   }
 
   for (int s0 = 0; s0 < Ls; s0 += SB) {
     __syncthreads();                                   // previous block's LDS reads are complete
     if (pf) {
-      tile_lstore(tileA, rs, pra, cpr, nchunks, tid);
-      tile_lstore(tileB, rs, prb, cpr, nchunks, tid);
+      tile_lstore(tileA, rs, pra, cpr, nchunks, tid, nthr);
+      tile_lstore(tileB, rs, prb, cpr, nchunks, tid, nthr);
     } else {
-      stage_tile<T>(tileA, rs, strA, strA_ld, s0, Ls, hd, hd_pad, tid, SB);
-      stage_tile<T>(tileB, rs, strB, strB_ld, s0, Ls, hd, hd_pad, tid, SB);
+      stage_tile<T>(tileA, rs, strA, strA_ld, s0, Ls, hd, hd_pad, tid, SB, nthr);
+      stage_tile<T>(tileB, rs, strB, strB_ld, s0, Ls, hd, hd_pad, tid, SB, nthr);
     }
     __syncthreads();
     // MODE 2: the streamed rows' statistics, loaded BEFORE the prefetch is issued (in-order vmcnt)
@@ -263,8 +264,8 @@ __global__ __launch_bounds__(256) void sdpa_kernel(SdpaArgs a) {
       }
     }
     if (pf && s0 + SB < Ls) {
-      tile_gload<T>(pra, strA, strA_ld, s0 + SB, Ls, hd, cpr, nchunks, tid);
-      tile_gload<T>(prb, strB, strB_ld, s0 + SB, Ls, hd, cpr, nchunks, tid);
+      tile_gload<T>(pra, strA, strA_ld, s0 + SB, Ls, hd, cpr, nchunks, tid, nthr);
+      tile_gload<T>(prb, strB, strB_ld, s0 + SB, Ls, hd, cpr, nchunks, tid, nthr);
     }
 
     f32x4 t1[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -434,11 +435,15 @@ int launch_mode(const SdpaArgs& a_in, hipStream_t st) {
   if (lds > 160 * 1024) return FAVIT_ERR_UNSUPPORTED;
   // output columns per workgroup: the largest of 16 / 32 / 64 / 128 that does not exceed the head dim
   const int ndt = a.hd >= 128 ? 8 : a.hd >= 64 ? 4 : a.hd >= 32 ? 2 : 1;
-  const dim3 grid((unsigned)((Lo + 63) / 64), (unsigned)(a.B * a.H), (unsigned)((a.hd + 16 * ndt - 1) / (16 * ndt)));
+  // 64 owner rows per workgroup (four waves), or 80 (five) where that saves workgroups: 65 tokens (ViT-Tiny on 32x32
+  // images) are ONE workgroup of five waves instead of a full one plus one that owns a single row
+  int nw = ((Lo + 79) / 80 < (Lo + 63) / 64) ? 5 : 4;
+  { const char* e = getenv("FAVIT_SDPA_WAVES"); if (e && (atoi(e) == 4 || atoi(e) == 5)) nw = atoi(e); }
+  const dim3 grid((unsigned)((Lo + 16 * nw - 1) / (16 * nw)), (unsigned)(a.B * a.H), (unsigned)((a.hd + 16 * ndt - 1) / (16 * ndt)));
 #define FAVIT_SDPA_LAUNCH(NDT)                                                                            \
   do {                                                                                                    \
     if (lds > 65536) favit_ensure_dyn_lds(reinterpret_cast<const void*>(sdpa_kernel<T, NDT, MODE>), lds); \
-    hipLaunchKernelGGL((sdpa_kernel<T, NDT, MODE>), grid, dim3(256), lds, st, a);                         \
+    hipLaunchKernelGGL((sdpa_kernel<T, NDT, MODE>), grid, dim3(64 * nw), lds, st, a);                     \
   } while (0)
   switch (ndt) {
     case 8: FAVIT_SDPA_LAUNCH(8); break;
