@@ -397,10 +397,14 @@ def _sdpa_views(favit, B, H, L, hd, t, col0, ld):
                                                   (2, 1, 33, 20, 64, "keys"), (1, 2, 197, 197, 64, None), (2, 1, 9, 9, 768, "full"),
                                                   (1, 3, 70, 100, 48, "keys"), (2, 2, 1, 1, 16, None), (1, 1, 130, 64, 192, None),
                                                   (2, 5, 64, 32, 128, "full")])
-def test_sdpa_fused_fwd_bwd(K, favit, dtype, B, H, Lq, Lk, hd, mask_kind):
+@pytest.mark.parametrize("waves", [0, 4, 5])
+def test_sdpa_fused_fwd_bwd(K, favit, dtype, B, H, Lq, Lk, hd, mask_kind, waves, monkeypatch):
     """The fused attention kernels (forward, dQ, dK/dV) against softmax(q k^T * scale, masked) v in fp32 torch:
     separate and interleaved operand layouts, both mask forms, head dims that need padding (16, 48) and
-    column chunking (192, 768), Lq != Lk, single-row problems."""
+    column chunking (192, 768), Lq != Lk, single-row problems; with the library's own choice of four or five waves
+    (64 / 80 owner rows) per workgroup and with either forced."""
+    if waves:
+        monkeypatch.setenv("FAVIT_SDPA_WAVES", str(waves))
     g = torch.Generator(device=DEV).manual_seed(B * 1000 + Lq * 10 + hd)
     D = H * hd
     V = favit.functional._View
