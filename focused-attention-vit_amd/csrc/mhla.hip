@@ -1386,7 +1386,9 @@ __device__ __forceinline__ int swz128(int slot, int boff) {        // byte `boff
   return slot * 128 + ((((boff >> 4) ^ slot) & 7) << 4) + (boff & 15);
 }
 
-template <bool PLAIN, int NIT>           // NIT: 16-byte chunks per thread and image pair (3: two or more tiles per block, W <= 7)
+// PLAIN: no mask and no dropout (compiled out).  NOMASK: no mask -- the interior fast paths apply; with dropout
+// (NOMASK && !PLAIN: the reference's training setting) they draw the keep decisions from the window position in closed form.
+template <bool PLAIN, int NIT, bool NOMASK = PLAIN>   // NIT: 16-byte chunks per thread and image pair (3: two or more tiles per block, W <= 7)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void mhla_bwd_lse_kernel(AttnArgs a) {
   constexpr int HD = 64;
   if (a.thresh) a.seed = favit_eff_seed(a.seed, a.epoch);
@@ -1501,7 +1503,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float lse_i = stat[2 * qslot];
     float pn[8], mult[8], dpn[8];
     // interior tile (wave-uniform): every row has its full window of W distinct keys, no wrap slots, no padding
-    const bool interior = PLAIN && t0 >= h && t0 + 15 + h <= L - 1;
+    const bool interior = NOMASK && t0 >= h && t0 + 15 + h <= L - 1;
     if (interior) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -1510,7 +1512,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const bool in = (slot < 16 + 2 * h) && (d >= -h) && (d <= h);
         mult[e] = in ? 1.f : 0.f;
         pn[e] = in ? __expf(S[e >> 2][e & 3] * inv_sq - lse_i) : 0.f;
-        dpn[e] = mult[e] * dP[e >> 2][e & 3];
+        float kwe = mult[e];
+        if (!PLAIN) {                                                   // dropout: window position of key j is d + h
+          const uint64_t idx = (((uint64_t)b * a.H + head) * L + i) * W + (uint64_t)(d + h);
+          kwe = (in && favit_keep(a.seed, idx, a.thresh)) ? a.keep_scale : 0.f;
+        }
+        dpn[e] = kwe * dP[e >> 2][e & 3];
       }
     } else {
 #pragma unroll
@@ -1614,7 +1621,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       tslot = nm + h + 1 + k;
     }
   };
-  const bool interior_keys = PLAIN && !has0 && !hasL;       // wave-uniform: band query slots only, multiplicity 0 / 1
+  const bool interior_keys = NOMASK && !has0 && !hasL;      // wave-uniform: band query slots only, multiplicity 0 / 1
   auto img_slot = [&](int qs) {                             // Q / dO image row (and statistics slot) of a query slot
     if (interior_keys) return main_slot(k0 - h + qs);       // (clamped: slots past the band carry multiplicity 0)
     int row, tslot, kind;
@@ -1650,11 +1657,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int qs = 16 * (e >> 2) + 4 * g + (e & 3);
       const int row = k0 - h + qs, d = qs - h - qi;                    // query row, query - key
       const int tslot = min(max(row, qm_lo), qm_hi - 1) - qm_lo;
-      const bool in = (qs < nband) && (row < L) && (j < L) && (d >= -h) && (d <= h);
+      const bool in = (qs < nband) && (row >= 0) && (row < L) && (j < L) && (d >= -h) && (d <= h);
       const float lse = stat[2 * tslot], dl = stat[2 * tslot + 1];
       const float pn = in ? __expf(T1[e >> 2][e & 3] * inv_sq - lse) : 0.f;
-      wds[e] = (bf16_t)(pn * (T2[e >> 2][e & 3] - dl) * inv_sq);
-      wp[e] = (bf16_t)pn;
+      float kwe = 1.f;
+      if (!PLAIN) {                                         // dropout: this key's position in the query row's window
+        const int lo = max(0, row - h), pad = W - (min(L, row + h + 1) - lo);
+        const int w0 = (lo == 0 || pad == 0) ? (j - lo) : pad + (j - lo);
+        const uint64_t idx = (((uint64_t)b * a.H + head) * L + row) * W + (uint64_t)w0;
+        kwe = (in && favit_keep(a.seed, idx, a.thresh)) ? a.keep_scale : 0.f;
+      }
+      wds[e] = (bf16_t)(pn * (kwe * T2[e >> 2][e & 3] - dl) * inv_sq);
+      wp[e] = (bf16_t)(pn * kwe);
     }
   } else {
 #pragma unroll
@@ -2070,9 +2084,11 @@ int attn_entry(bool bwd, const void* qkv, const void* dout, void* out, const uin
     const bool three = cap_kv * 8 <= 3 * 64 * nw && cap_q * 8 <= 3 * 64 * nw;         // chunks per thread and image pair
     if (three) {
       if (plain) hipLaunchKernelGGL((mhla_bwd_lse_kernel<true, 3>), grid, dim3(64 * nw), lds, st, a3);
+      else if (mask == nullptr) hipLaunchKernelGGL((mhla_bwd_lse_kernel<false, 3, true>), grid, dim3(64 * nw), lds, st, a3);
       else hipLaunchKernelGGL((mhla_bwd_lse_kernel<false, 3>), grid, dim3(64 * nw), lds, st, a3);
     } else {
       if (plain) hipLaunchKernelGGL((mhla_bwd_lse_kernel<true, 5>), grid, dim3(64 * nw), lds, st, a3);
+      else if (mask == nullptr) hipLaunchKernelGGL((mhla_bwd_lse_kernel<false, 5, true>), grid, dim3(64 * nw), lds, st, a3);
       else hipLaunchKernelGGL((mhla_bwd_lse_kernel<false, 5>), grid, dim3(64 * nw), lds, st, a3);
     }
     FAVIT_CHECK_LAUNCH();
