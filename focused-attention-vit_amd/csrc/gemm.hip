@@ -1665,17 +1665,35 @@ __global__ __launch_bounds__(256) void grouped_reduce_kernel(ReduceParams rp) {
   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
     const long e = 4 * q;
     const float* src = rp.ws + sg.off + e;
+    // slabs in groups of eight: the loads of a group are all in flight before the first add (with one load per
+    // loop trip every slab was a round trip of its own: 3.0 TB/s at ViT-Base, where the 227 MB of slabs no longer
+    // sit in the Infinity Cache); the additions keep the split order, so the result is bit-identical
+    const long r = e / sg.cols, c = e - r * sg.cols;   // cols % 4 == 0 (or the segment is one contiguous vector)
+    float* d = sg.dst + r * sg.ld + c;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sg.accumulate) o = *reinterpret_cast<const float4*>(d);
     float4 acc = *reinterpret_cast<const float4*>(src);
-    for (int sidx = 1; sidx < rp.nsplit; ++sidx) {
+    int sidx = 1;
+    for (; sidx + 7 < rp.nsplit; sidx += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long)(sidx + u) * rp.slab_stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    if (sidx + 6 < rp.nsplit) {                         // 7 left (8 splits: the common short-token case)
+      float4 v[7];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long)(sidx + u) * rp.slab_stride);
+#pragma unroll
+      for (int u = 0; u < 7; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+      sidx += 7;
+    }
+    for (; sidx < rp.nsplit; ++sidx) {
       const float4 v = *reinterpret_cast<const float4*>(src + (long)sidx * rp.slab_stride);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    const long r = e / sg.cols, c = e - r * sg.cols;   // cols % 4 == 0 (or the segment is one contiguous vector)
-    float* d = sg.dst + r * sg.ld + c;
-    if (sg.accumulate) {
-      const float4 o = *reinterpret_cast<const float4*>(d);
-      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
-    }
+    if (sg.accumulate) { acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
     *reinterpret_cast<float4*>(d) = acc;
   }
 }
