@@ -2221,20 +2221,27 @@ long grouped_slab_floats(const favit_gemm_t* gs, int count) {
   return (tot + 63) / 64 * 64;
 }
 
-// splits = 8*s: one group of s splits per XCD; the s <= 4 that fills the 64 workgroup slots of an XCD best among
-// those that leave every split at least one K-step (short token counts: fewer splits, not a refusal).
+// splits = 8*s: one group of s splits per XCD.  The s <= 4 that minimises a two-term cost per output element among
+// those that leave every split at least one K-step (short token counts: fewer splits, not a refusal):
+//   main loops  2 K / (util(s) * 1.0 PF)      util = how full the last round of an XCD's 64 workgroup slots is
+//   slabs       8 s * 4 B * 2 / 4 TB/s        written by the tiles' epilogues, read back by the reduction
+// Round 2 maximised util alone and took 16 splits at ViT-Base (216 tiles: util 0.96 against 0.84): 453 MB of slabs per
+// block written and re-read instead of 227 -- cfg4 29.9 ms per step against 28.7 with 8 (and 31.3 / 32.7 with 24 / 32).
 // Returns 0 if even 8 splits do not fit.
 long grouped_nsplit(long total_tiles, long K, long* kps_out) {
-  double best = -1.0;
+  double best = 0.0;
   long best_s = 0, best_kps = 0;
-  for (long s = 1; s <= 4; ++s) {
+  long s_lo = 1, s_hi = 4;
+  { const char* e = getenv("FAVIT_GROUPED_S"); if (e && atoi(e) >= 1 && atoi(e) <= 4) s_lo = s_hi = atoi(e); }   // A/B: force 8 * s splits
+  for (long s = s_lo; s <= s_hi; ++s) {
     const long nsplit = 8 * s;
     long kps = (K + nsplit - 1) / nsplit;
     kps = ((kps + P4_BK - 1) / P4_BK) * P4_BK;
     if ((nsplit - 1) * kps >= K) continue;            // the last split would be empty
     const long w = total_tiles * s;
     const double util = (double)w / (double)(((w + 63) / 64) * 64);
-    if (util > best + 0.02) { best = util; best_s = s; best_kps = kps; }
+    const double cost = 2.0 * (double)K / (util * 1.0e15) + 64.0 * (double)s / 4.0e12;
+    if (best_s == 0 || cost < best) { best = cost; best_s = s; best_kps = kps; }
   }
   if (kps_out) *kps_out = best_kps;
   return 8 * best_s;
