@@ -134,15 +134,17 @@ CONFIGS = {
 }
 
 
-def build_model(pkg, cfg, dev, dropout=0.0):
+def build_model(pkg, cfg, dev, dropout=0.0, attn_dropout=0.0, embed_dropout=0.0):
+    """The reference's dropout defaults are dropout 0.1, attn_dropout 0.0, embed_dropout 0.0 (main.py:106-111,
+    experiments/mhla_pretrained.py:49-50): --dropout sets only the first; the other two have flags of their own."""
     M = pkg.models
-    d = float(dropout)
+    d, da, de = float(dropout), float(attn_dropout), float(embed_dropout)
     if cfg == "cfg1":
         return M.vit.VisionTransformer(img_size=32, patch_size=4, num_classes=10, embed_dim=192, depth=12, num_heads=3).to(dev)
     if cfg == "cfg2":
         return M.vit_mhla.VisionTransformerMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12,
                                                 num_heads=6, window_size=7, use_mhla=True, dropout=d,
-                                                attn_dropout=d, embed_dropout=d).to(dev)
+                                                attn_dropout=da, embed_dropout=de).to(dev)
     if cfg in ("cfg3", "cfg5"):
         m = M.sppp_mhla.SPPPViTMHLA(img_size=224, patch_size=16, num_classes=1000, embed_dim=384, depth=12, num_heads=6,
                                     num_superpixels=16, pooling_type="mean", window_size=7, use_mhla=True)
@@ -155,8 +157,8 @@ def build_model(pkg, cfg, dev, dropout=0.0):
                     p_.requires_grad = False
         return m.to(dev)
     return M.vit_mhla.VisionTransformerMHLA(img_size=384, patch_size=16, num_classes=1000, embed_dim=768, depth=12,
-                                            num_heads=12, window_size=7, use_mhla=True, dropout=d, attn_dropout=d,
-                                            embed_dropout=d).to(dev)
+                                            num_heads=12, window_size=7, use_mhla=True, dropout=d, attn_dropout=da,
+                                            embed_dropout=de).to(dev)
 
 
 def host_cores():
@@ -174,6 +176,12 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return max(1, n)
+
+
+def active_knobs():
+    """FAVIT_* environment variables set for this process: kernel-selection / debugging switches the library or the
+    package reads.  A clean measurement has none."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("FAVIT_")}
 
 
 def log(msg):
@@ -275,8 +283,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="cfg1 / cfg3: eager launches instead of the replayed HIP graph")
     ap.add_argument("--side-stream", action="store_true", help="run weight-gradient GEMMs on a second HIP stream")
     ap.add_argument("--dropout", type=float, default=0.0,
-                    help="dropout = attn_dropout = embed_dropout of the cfg2 / cfg4 models (the reference's main.py:106 "
-                         "trains with 0.1; the headline row is 0.0, SURVEY 8d)")
+                    help="`dropout` of the cfg2 / cfg4 models: MLP, projection and residual-branch sites (the reference's "
+                         "main.py:106 trains with 0.1 and attn_dropout = embed_dropout = 0.0; the headline row is 0.0, SURVEY 8d)")
+    ap.add_argument("--attn-dropout", type=float, default=0.0, help="`attn_dropout` (reference default 0.0, main.py:108)")
+    ap.add_argument("--embed-dropout", type=float, default=0.0, help="`embed_dropout` (reference default 0.0, main.py:110)")
     ap.add_argument("--bucket-mb", type=float, default=0.0, help="all-reduce bucket size in MiB (default: dp.GradSync's own choice)")
     ap.add_argument("--slic", action="store_true",
                     help="cfg3: also time the step WITH the device SLIC inside it (label maps recomputed from the batch every "
@@ -312,8 +322,9 @@ def main():
     pkg.set_side_stream(args.side_stream)
 
     torch.manual_seed(1234)
-    model = build_model(pkg, args.config, dev, args.dropout)
+    model = build_model(pkg, args.config, dev, args.dropout, args.attn_dropout, args.embed_dropout)
     model.train()
+    health = pkg.train.Health(dev)                   # first non-finite loss / gradient / parameter, noted by the kernels
     B = args.batch or c["batch"]
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn(B, 3, c["img"], c["img"], device=dev, generator=g)
@@ -379,7 +390,10 @@ def main():
     e_begin, e_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e_begin.record()
+    poison_at = int(os.environ.get("FAVIT_BENCH_TEST_POISON_STEP", "-1"))   # tests only: exercises the non-finite report
     for s in range(args.steps):
+        if s == poison_at:
+            opt.groups[0]["flat"].flat_p[7].fill_(float("nan"))
         loss = step()
     e_end.record()
     sync()
@@ -391,6 +405,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     loss_val = float(loss.item())
+    # A poisoned run is not a measurement: name what went non-finite and where, keep the evidence, print NO metric line.
+    bad = health.poll()
+    if bad is not None or not np.isfinite(loss_val):
+        rep = health.report(opt, model, extra=[("loss", loss)]) or {}
+        rep.update({"loss": loss_val, "config": args.config, "dtype": args.dtype, "steps": args.steps, "warmup": args.warmup,
+                    "rank": rank, "world": world, "hip_graph": bool(graphed), "seed": 1234 + rank,
+                    "adamw_launches_per_step": len(opt.groups), "knobs": active_knobs()})
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, f"nonfinite_{args.config}_rank{rank}_{int(time.time())}.json")
+        with open(path, "w") as fh:
+            json.dump(rep, fh, indent=1)
+        log(f"NON-FINITE values in the step: {json.dumps(rep)}  (written to {path})")
+        sys.exit(3)
 
     # PCIe-inclusive rate (informational): every step consumes a fresh uint8 batch from pinned host memory
     pcie = None
@@ -495,7 +523,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{c['name']}, {B} images/GPU; step = fwd + cross-entropy + bwd + grad all-reduce + AdamW",
                        "global_batch": world * B, "parallelism": f"dp{world}", "weights": "random-init (seed 1234)",
-                       "baseline_config": args.config, "hip_graph": bool(graphed), "dropout": args.dropout},
+                       "baseline_config": args.config, "hip_graph": bool(graphed), "dropout": args.dropout,
+                       "attn_dropout": args.attn_dropout, "embed_dropout": args.embed_dropout},
+            "knobs": active_knobs(),
             "gpu_ms_per_step_events": round(e_begin.elapsed_time(e_end) / args.steps, 3),
             "loss": round(loss_val, 5),
             "model_tflops_per_s": round(n_img * flops_per_image_train(**c["flops"]) / dt / 1e12, 2),

@@ -54,6 +54,7 @@ _SIGS = {
     "favit_abi_version": ([], C.c_int),
     "favit_strerror": ([C.c_int], C.c_char_p),
     "favit_set_dropout_epoch": ([vp], C.c_int),
+    "favit_set_health_word": ([vp], C.c_int),
     "favit_gemm": ([C.POINTER(GemmDesc), vp], C.c_int),
     "favit_gemm_last_kernel": ([], C.c_char_p),
     "favit_gemm_grouped_tn": ([C.POINTER(GemmDesc), i32, vp], C.c_int),

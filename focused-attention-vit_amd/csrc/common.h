@@ -48,6 +48,36 @@ static inline void favit_ensure_dyn_lds(const void* kernel, int bytes) {
   done.push_back({kernel, dev, bytes});
 }
 
+// Zero-fill as a KERNEL, never hipMemsetAsync.  A hipMemsetAsync captured into a HIP graph (train.GraphedStep) came
+// back wrong from the SECOND replay on (ROCm 7.2, gfx950): dword 2 of every 16 bytes of the destination held one
+// arbitrary constant (3e19, -6e20, 1e25: another value in every process) instead of zero, while the eager call and the
+// first replay were right (tools/graph_memset_probe.py shows it without any kernel of this library).  The cls_token /
+// pos_embed gradients (atomics on top of that "zero") therefore overflowed AdamW's second moment and silently froze
+// both parameters in every graph-replayed step -- and when the constant happened to be a NaN pattern the loss went NaN
+// (the two unexplained NaN losses of round 3).  Found with tools/poison.py; pinned by
+// tests/test_gpu_kernels.py::test_zero_fills_survive_graph_replays.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void favit_zero_kernel(unsigned char* __restrict__ p, long bytes) {
+  // p + head is 16-byte aligned; body in 16-byte stores, head / tail bytewise
+  const long head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;
+  const long h = head < bytes ? head : bytes;
+  const long n16 = (bytes - h) >> 4;
+  uint4* b = reinterpret_cast<uint4*>(p + h);
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+  for (long i = tid; i < n16; i += nth) b[i] = make_uint4(0u, 0u, 0u, 0u);
+  const long tail0 = h + (n16 << 4);
+  if (tid < h) p[tid] = 0;
+  if (tid < bytes - tail0) p[tail0 + tid] = 0;
+}
+static inline hipError_t favit_zero_async(void* ptr, size_t bytes, hipStream_t st) {
+  if (!ptr || bytes == 0) return hipSuccess;
+  long blocks = (long)((bytes / 16 + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(favit_zero_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<unsigned char*>(ptr), (long)bytes);
+  return hipGetLastError();
+}
+
 template <typename T> struct dtype_of;
 template <> struct dtype_of<float> { static constexpr int value = FAVIT_F32; };
 template <> struct dtype_of<bf16_t> { static constexpr int value = FAVIT_BF16; };

@@ -2232,8 +2232,8 @@ extern "C" int favit_mhla_fold_bwd(const float* dweff, const float* dbeff, const
   const int hd = D / H;
   hipStream_t st = as_stream(stream);
   if (!accumulate) {
-    (void)hipMemsetAsync(dwl, 0, sizeof(float) * hd * hd, st);
-    (void)hipMemsetAsync(dbl, 0, sizeof(float) * hd, st);
+    (void)favit_zero_async(dwl, sizeof(float) * hd * hd, st);
+    (void)favit_zero_async(dbl, sizeof(float) * hd, st);
   }
   const int gwx = (D + 1 + FOLD_TC - 1) / FOLD_TC, gwy = 2 * H + (D + hd - 1) / hd;      // fold_w grid
   const int glx = 2 * H, gly = FOLD_L_SPLIT;                                             // fold_bwd_l grid

@@ -4,6 +4,8 @@
 // the row in registers (one 64-lane wave per token row, shuffle reductions).
 #include "common.h"
 
+extern "C" unsigned* favit_health_ptr_(void);
+
 namespace {
 
 // ---------------------------------------------------------------------------------
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(256) void embed_prologue_bwd_chunk_kernel(const flo
 __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits,
                                                             const int64_t* __restrict__ labels,
                                                             float* __restrict__ loss_rows, float* __restrict__ dlogits,
-                                                            int B, int C, float grad_scale) {
+                                                            int B, int C, float grad_scale, unsigned* __restrict__ health) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= B) return;
@@ -508,7 +510,12 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
   const int64_t lab64 = labels[row];
   const bool lab_ok = lab64 >= 0 && lab64 < C;       // out of range (e.g. ignore_index): NaN row, never an OOB read
   const int lab = lab_ok ? (int)lab64 : -1;
-  if (lane == 0) loss_rows[row] = lab_ok ? lse - lr[lab] : __builtin_nanf("");
+  if (lane == 0) {
+    const float lrow = lab_ok ? lse - lr[lab] : __builtin_nanf("");
+    loss_rows[row] = lrow;
+    // health word (favit_set_health_word): a non-finite loss row of an in-range label = non-finite logits
+    if (health && lab_ok && !isfinite(lrow) && !(atomicOr(health, 1u) & 1u)) health[1] = health[3] + 1;
+  }
   if (dlogits) {
     const float inv = 1.0f / s;
     for (int c = lane; c < C; c += 64)
@@ -519,8 +526,9 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
 // torch.optim.AdamW semantics (decoupled weight decay), one flat fp32 chunk
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, bf16_t* __restrict__ p_lp, long n, float lr, float b1, float b2,
-                             float eps, float wd, float bc1, float bc2, float gscale) {
+                             float eps, float wd, float bc1, float bc2, float gscale, unsigned* __restrict__ health) {
   const float step = lr / bc1, rbc2 = rsqrtf(bc2);
+  bool bad_g = false, bad_p = false;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
     float pi = p[i] * (1.0f - lr * wd);
@@ -529,6 +537,18 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     pi -= step * mi / (sqrtf(vi) * rbc2 + eps);
     p[i] = pi; m[i] = mi; v[i] = vi;
     if (p_lp) p_lp[i] = (bf16_t)pi;
+    bad_g |= !isfinite(gi);
+    bad_p |= !isfinite(pi);
+  }
+  // Health word (favit_set_health_word; null = off): the update reads every gradient and writes every parameter
+  // anyway, so noticing the first non-finite one costs two compares per element and no memory traffic.  [0] flags
+  // (1 loss row, 2 gradient, 4 updated parameter), [1] / [2] value of the AdamW launch counter [3] (+1) when the
+  // flag bits 1 / (2|4) were first set, [3] AdamW launches so far.  A clean run performs no atomic at all.
+  if (health) {
+    const unsigned f = (bad_g ? 2u : 0u) | (bad_p ? 4u : 0u);
+    if (f && !(atomicOr(health, f) & 6u)) health[2] = health[3] + 1;
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(health + 3, 1u);   // (stream order: one AdamW launch at a time)
   }
 }
 
@@ -753,8 +773,8 @@ extern "C" int favit_embed_prologue_bwd(const float* dx, void* dtok, int dtok_dt
       (reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (!dtok || (reinterpret_cast<uintptr_t>(dtok) & 15) == 0)) {
     // large batches: split the batch over grid.y (the one-thread-per-element kernel below walks all B
     // images serially with 4-byte accesses: 119 us at B = 256, L = 197, D = 384)
-    if (dpos) (void)hipMemsetAsync(dpos, 0, sizeof(float) * total, st);
-    if (dcls) (void)hipMemsetAsync(dcls, 0, sizeof(float) * D, st);
+    if (dpos) (void)favit_zero_async(dpos, sizeof(float) * total, st);
+    if (dcls) (void)favit_zero_async(dcls, sizeof(float) * D, st);
     const int chunks = B >= 128 ? 16 : 4, bchunk = (B + chunks - 1) / chunks;
     const dim3 grid((unsigned)((total / 4 + 255) / 256), (unsigned)chunks);
     if (dtok_dtype == FAVIT_F32)
@@ -777,7 +797,7 @@ extern "C" int favit_embed_prologue_bwd(const float* dx, void* dtok, int dtok_dt
 extern "C" int favit_cross_entropy(const float* logits, const int64_t* labels, float* loss_rows, float* dlogits,
                                    int32_t B, int32_t C, float grad_scale, void* stream) {
   if (!logits || !labels || !loss_rows || B <= 0 || C <= 0) return FAVIT_ERR_INVALID;
-  hipLaunchKernelGGL(cross_entropy_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), logits, labels, loss_rows, dlogits, B, C, grad_scale);
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3((B + 3) / 4), dim3(256), 0, as_stream(stream), logits, labels, loss_rows, dlogits, B, C, grad_scale, favit_health_ptr_());
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }
@@ -787,7 +807,7 @@ extern "C" int favit_adamw(float* p, const float* g, float* m, float* v, void* p
                            float grad_scale, void* stream) {
   if (!p || !g || !m || !v || n < 0) return FAVIT_ERR_INVALID;
   if (n == 0) return FAVIT_OK;
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), p, g, m, v, (bf16_t*)p_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, grad_scale);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), p, g, m, v, (bf16_t*)p_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2, grad_scale, favit_health_ptr_());
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }
@@ -800,6 +820,15 @@ extern "C" const unsigned long long* favit_dropout_epoch_ptr_(void) { return g_d
 extern "C" int favit_set_dropout_epoch(const uint64_t* device_word) {
   if (reinterpret_cast<uintptr_t>(device_word) & 7) return FAVIT_ERR_ALIGN;
   g_drop_epoch = reinterpret_cast<const unsigned long long*>(device_word);
+  return FAVIT_OK;
+}
+
+// process-wide health word (4 x uint32 on the device, or null): see adamw_kernel
+static unsigned* g_health = nullptr;
+extern "C" unsigned* favit_health_ptr_(void) { return g_health; }
+extern "C" int favit_set_health_word(uint32_t* device_words) {
+  if (reinterpret_cast<uintptr_t>(device_words) & 15) return FAVIT_ERR_ALIGN;
+  g_health = device_words;
   return FAVIT_OK;
 }
 

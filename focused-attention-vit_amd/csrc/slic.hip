@@ -576,7 +576,7 @@ extern "C" int favit_slic_cluster(const int16_t* feat, uint8_t* labels, const in
   if (reinterpret_cast<uintptr_t>(ws) & 7) return FAVIT_ERR_ALIGN;
   hipStream_t st = as_stream(stream);
   const long HW = (long)H * W;
-  if (hipMemsetAsync(labels, 0, (size_t)B * HW, st) != hipSuccess) return FAVIT_ERR_LAUNCH;
+  if (favit_zero_async(labels, (size_t)B * HW, st) != hipSuccess) return FAVIT_ERR_LAUNCH;
   hipLaunchKernelGGL(slic_seed_kernel, dim3((unsigned)B), dim3(64), 0, st, reinterpret_cast<const short*>(feat), init_yx, ws, K, H, W);
   FAVIT_CHECK_LAUNCH();
   const dim3 grid((unsigned)((HW + ASG_TILE - 1) / ASG_TILE), (unsigned)B);

@@ -125,6 +125,58 @@ class FusedAdamW:
         F.bump_weight_epoch([g["mirror"] for g in self.groups if g["mirror"] is not None])
 
 
+class Health:
+    """The library's health word (include/favit.h: favit_set_health_word): four device counters in which the
+    cross-entropy and AdamW kernels note the FIRST non-finite loss row / gradient / updated parameter they meet, at no
+    cost in a clean run.  `poll()` is a host sync; call it every N steps, or once after a timed region.  With
+    `opt`, `report()` also walks the optimizer's flat buffers and names the first non-finite tensor."""
+
+    def __init__(self, device=None):
+        from . import _abi
+        self.words = torch.zeros(4, dtype=torch.int32, device=device if device is not None else torch.cuda.current_device())
+        _abi.check(_abi.lib().favit_set_health_word(self.words.data_ptr()), "favit_set_health_word")
+
+    def close(self):
+        from . import _abi
+        _abi.check(_abi.lib().favit_set_health_word(None), "favit_set_health_word")
+
+    def poll(self):
+        """None while everything was finite, else a dict (kinds, first AdamW launch index, launches so far)."""
+        f, first_loss, first_grad, launches = (int(v) & 0xFFFFFFFF for v in self.words.tolist())
+        if f == 0:
+            return None
+        kinds = [k for b, k in ((1, "loss"), (2, "gradient"), (4, "parameter")) if f & b]
+        return {"non_finite": kinds, "adamw_launch_of_first_bad_loss": first_loss or None,
+                "adamw_launch_of_first_bad_gradient_or_parameter": first_grad or None, "adamw_launches": launches}
+
+    def report(self, opt: "FusedAdamW" = None, model: torch.nn.Module = None, extra=()):
+        """poll() plus, per optimizer group, the first non-finite entry of flat_p / flat_g / m / v mapped back to a
+        parameter name (and of any (name, tensor) in `extra`)."""
+        out = self.poll() or {}
+        names = {}
+        if model is not None:
+            names = {id(p): n for n, p in model.named_parameters()}
+        found = []
+        for gi, g in enumerate(opt.groups if opt is not None else ()):
+            flat = g["flat"]
+            for key, t in (("flat_g", flat.flat_g), ("flat_p", flat.flat_p), ("m", g["m"]), ("v", g["v"])):
+                bad = (~torch.isfinite(t)).nonzero()
+                if bad.numel():
+                    idx = int(bad[0])
+                    who = "?"
+                    for p_, o in zip(flat.params, flat.offsets):
+                        if o <= idx < o + p_.numel():
+                            who = names.get(id(p_), f"param@{o}")
+                            break
+                    found.append({"group": gi, "buffer": key, "count": int(bad.shape[0]), "first_index": idx, "parameter": who})
+        for n, t in extra:
+            if t is not None and torch.is_tensor(t) and t.is_floating_point() and not bool(torch.isfinite(t).all()):
+                found.append({"tensor": n, "count": int((~torch.isfinite(t)).sum())})
+        if found:
+            out["tensors"] = found
+        return out or None
+
+
 def train_step(model, images, labels, opt: FusedAdamW):
     """One step of the reference's hot loop; returns the (device) loss tensor, no host sync."""
     opt.zero_grad()

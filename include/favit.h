@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FAVIT_ABI_VERSION 6
+#define FAVIT_ABI_VERSION 7
 #define FAVIT_FP8_AMAX_SLOTS 256   /* partial maxima per tensor with delayed fp8 scaling (favit_fp8_quantize) */
 
 enum { FAVIT_F32 = 0, FAVIT_BF16 = 1, FAVIT_FP8 = 2 };
@@ -61,6 +61,16 @@ const char* favit_strerror(int code);
  * graph's first node incrementing the word, every replay still draws fresh masks, and the forward and backward
  * kernels of one replay (which recompute the same masks) agree.  Process-wide; the caller owns the word. */
 int favit_set_dropout_epoch(const uint64_t* device_word);
+
+/* Health word (v7): `device_words` = four zero-initialised uint32 on the device (16-byte aligned), or NULL to switch
+ * it off.  favit_cross_entropy and favit_adamw -- which read every logit row / every gradient and write every
+ * parameter anyway -- note the FIRST non-finite value they meet, at no memory traffic and without atomics in a clean
+ * run:  [0] flags: 1 = a loss row of an in-range label was non-finite (non-finite logits), 2 = a gradient handed to
+ * AdamW was non-finite, 4 = an updated parameter is non-finite;  [1] = (AdamW launches so far) + 1 when bit 1 was
+ * first set, [2] = the same for bits 2 | 4, [3] = AdamW launches so far.  bench.py registers one and refuses to print
+ * a metric line for a poisoned run; a harness can poll it every N steps without synchronising per step.  Process-wide;
+ * the caller owns the words (and keeps them alive while captured HIP graphs hold their address). */
+int favit_set_health_word(uint32_t* device_words);
 
 /* ------------------------------------------------------------------------------------
  * GEMM with fused epilogue: every nn.Linear on the path and the dense QK^T / attn.V

@@ -14,6 +14,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("FAVIT_POISON") and torch.cuda.is_available():
+        # one deterministic pass of the suite on poisoned LDS / slab workspace / fresh allocations (tools/poison.py)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        importlib.import_module("poison").install()
 
 
 def pytest_collection_modifyitems(config, items):

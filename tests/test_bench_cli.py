@@ -36,6 +36,7 @@ def _check(j, steps, warmup, dtype="bf16"):
     assert r["bound"] in ("mfma", "hbm") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     import math
     assert math.isfinite(j["loss"])
+    assert j["knobs"] == {k: v for k, v in os.environ.items() if k.startswith("FAVIT_") and k != "FAVIT_DP_FORCE"}
 
 
 @pytest.mark.parametrize("cfg,extra", [("cfg2", ["--batch", "16"]), ("cfg2", ["--batch", "16", "--dropout", "0.1"]),
@@ -52,6 +53,28 @@ def test_bench_line(cfg, extra):
         assert j["config"]["hip_graph"] is True and "R = 16 / R = 15" in j["config"]["workload"]
     if "--dropout" in extra:
         assert j["config"]["dropout"] == 0.1
+
+
+def test_bench_refuses_to_report_a_non_finite_run(tmp_path):
+    """A poisoned run is not a measurement: bench.py exits non-zero WITHOUT a metric line, names the first non-finite
+    tensor and the AdamW launch it appeared at (the library's health word), and leaves the record under gpurun_out/."""
+    env = dict(os.environ, FAVIT_BENCH_TEST_POISON_STEP="2")
+    env.pop("FAVIT_POISON", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg1", "--steps", "4", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 3, (out.returncode, out.stderr[-1500:])
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "NON-FINITE" in out.stderr
+    line = [l for l in out.stderr.splitlines() if "NON-FINITE" in l][0]
+    rep = json.loads(line.split("NON-FINITE values in the step: ", 1)[1].rsplit("  (written to", 1)[0])
+    # 1 warm-up step + timed step 0, 1 are clean; the poison goes in before timed step 2 = the 4th AdamW launch round
+    per = rep["adamw_launches_per_step"]
+    assert rep["adamw_launch_of_first_bad_gradient_or_parameter"] in range(3 * per + 1, 4 * per + 2)
+    assert any(t.get("buffer") == "flat_p" for t in rep["tensors"])
+    assert rep["knobs"] == {"FAVIT_BENCH_TEST_POISON_STEP": "2"}
+    path = line.rsplit("(written to ", 1)[1].rstrip(")")
+    assert os.path.exists(path)
+    os.remove(path)
 
 
 def test_bench_cpu_baseline_leg():

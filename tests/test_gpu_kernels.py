@@ -507,6 +507,87 @@ def test_cross_entropy_and_adamw(K):
     assert torch.equal(lp, p.to(torch.bfloat16))
 
 
+def test_zero_fills_survive_graph_replays(K):
+    """The launches that zero a destination and then add into it with atomics (embed-prologue backward: cls_token /
+    pos_embed gradients; latent_proj fold backward), captured ONCE in a HIP graph and replayed: every replay equals the
+    eager result.  With hipMemsetAsync as the zero-fill the second and later replays came back with dword 2 of every 16
+    bytes at an arbitrary huge constant (ROCm 7.2 graph memset nodes; tools/graph_memset_probe.py) -- the cause of the
+    frozen pos_embed and of the rare NaN losses of graph-replayed steps."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, N, D, H = 64, 64, 192, 3
+    dx = torch.randn(B, N + 1, D, device=DEV, generator=g)
+    ref_tok, ref_cls, ref_pos = K.embed_prologue_bwd(dx, B, N, D, torch.bfloat16)
+    assert rel_l2(ref_pos, dx.sum(0)) < 1e-5 and rel_l2(ref_cls, dx[:, 0].sum(0)) < 1e-5
+    hd = D // H
+    dweff = torch.randn(3 * D, D, device=DEV, generator=g)
+    dbeff = torch.randn(3 * D, device=DEV, generator=g)
+    wqkv = torch.randn(3 * D, D, device=DEV, generator=g) * 0.05
+    bqkv = torch.randn(3 * D, device=DEV, generator=g) * 0.05
+    wl = torch.randn(hd, hd, device=DEV, generator=g) * 0.1
+    ref_fold = K.mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        K.embed_prologue_bwd(dx, B, N, D, torch.bfloat16)
+        K.mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        tok, cls, pos = K.embed_prologue_bwd(dx, B, N, D, torch.bfloat16)
+        fold = K.mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H)
+    for rep in range(4):
+        for t in (cls, pos, fold[2], fold[3]):
+            t.fill_(7.0)                                  # whatever the previous replay (or anybody) left there
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(tok, ref_tok), rep
+        # (atomics: order-dependent rounding only)
+        assert rel_l2(pos, ref_pos) < 1e-6 and rel_l2(cls, ref_cls) < 1e-6, rep
+        assert float((pos - ref_pos).abs().max()) < 1e-3 and float((cls - ref_cls).abs().max()) < 1e-3, rep
+        for a, b in zip(fold, ref_fold):
+            assert rel_l2(a, b) < 1e-5 and float((a - b).abs().max()) < 1e-2 * float(b.abs().max()), rep
+
+
+def test_health_word_notes_first_non_finite_loss_gradient_and_parameter(favit, K):
+    """include/favit.h favit_set_health_word: clean calls leave the four words at (0, 0, 0, launches); a NaN gradient,
+    an inf logit row and an overflowing parameter are each noted with the AdamW launch index they first appeared at."""
+    h = favit.train.Health(torch.device(DEV))
+    try:
+        p = torch.randn(5000, device=DEV)
+        g = torch.randn_like(p)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        logits = torch.randn(9, 10, device=DEV)
+        labels = torch.randint(0, 10, (9,), device=DEV)
+        for step in (1, 2):
+            K.cross_entropy(logits, labels, grad_scale=1.0)
+            K.adamw(p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.05, step)
+        assert h.poll() is None and h.words.tolist() == [0, 0, 0, 2]
+        # out-of-range label: a NaN loss row by contract, NOT a health event
+        K.cross_entropy(logits, torch.full_like(labels, -100), grad_scale=1.0)
+        assert h.poll() is None
+        g2 = g.clone()
+        g2[4321] = float("nan")
+        K.adamw(p, g2, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.05, 3)           # launch 3: gradient and parameter go bad
+        r = h.poll()
+        # (block 0 counts the launch when IT is done: blocks that finish later read the counter one higher)
+        assert r["non_finite"] == ["gradient", "parameter"] and r["adamw_launch_of_first_bad_gradient_or_parameter"] in (3, 4)
+        assert r["adamw_launches"] == 3 and r["adamw_launch_of_first_bad_loss"] is None
+        bad_logits = logits.clone()
+        bad_logits[5, 3] = float("inf")
+        K.cross_entropy(bad_logits, labels, grad_scale=1.0)
+        r = h.poll()
+        assert r["non_finite"] == ["loss", "gradient", "parameter"] and r["adamw_launch_of_first_bad_loss"] == 4
+        K.adamw(p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.05, 4)            # later launches do not move the first-event marks
+        r = h.poll()
+        assert r["adamw_launch_of_first_bad_gradient_or_parameter"] in (3, 4) and r["adamw_launches"] == 4
+    finally:
+        h.close()
+    # switched off: the kernels run without the word
+    K.adamw(p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.05, 5)
+    assert h.words.tolist()[3] == 4
+
+
 def test_sppp_kernels_vs_golden(K):
     from conftest import case, load_golden
     SP = load_golden("sppp.npz")

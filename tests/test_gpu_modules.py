@@ -469,6 +469,53 @@ def test_graphed_step_matches_eager_steps(favit):
     assert rel_l2(w2.cpu(), w1.cpu()) < 1e-3
 
 
+@pytest.mark.parametrize("kind", ["vit", "vit_mhla"])
+def test_graphed_step_per_parameter_and_optimizer_state_at_bench_like_batch(favit, kind):
+    """As above at a batch that takes the chunked embed-prologue backward (B >= 32: zero-fill + atomics for the
+    cls_token / pos_embed gradients), compared PER PARAMETER and in the optimizer's moments after four replays.  The
+    concatenated-weights comparison above cannot see one small parameter going wrong: with the zero-fill as a captured
+    hipMemsetAsync the pos_embed / cls_token gradients of every replay after the first carried a huge constant in every
+    fourth element, AdamW's second moment overflowed to inf and both parameters silently stopped training."""
+    favit.set_compute_dtype("bf16")
+
+    def build():
+        torch.manual_seed(12)
+        if kind == "vit":
+            m = favit.models.vit.VisionTransformer(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2, num_heads=2)
+        else:
+            m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=64,
+                                                            depth=2, num_heads=4, use_mhla=True)
+        m = m.to(DEV).train()
+        opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=1e-3), lr=1e-3, weight_decay=0.05, distributed=False)
+        return m, opt
+    g = torch.Generator(device=DEV).manual_seed(3)
+    xs = [torch.randn(64, 3, 32, 32, device=DEV, generator=g) for _ in range(4)]
+    ys = [torch.randint(0, 10, (64,), device=DEV, generator=g) for _ in range(4)]
+    m1, o1 = build()
+    for x, y in zip(xs, ys):
+        favit.train.train_step(m1, x, y, o1)
+    m2, o2 = build()
+    step = favit.train.GraphedStep(m2, o2, xs[0], ys[0])
+    for x, y in zip(xs, ys):
+        step(x, y)
+    torch.cuda.synchronize()
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert bool(torch.isfinite(p2).all()) and bool(torch.isfinite(p2.grad).all()), n
+        assert float(p2.grad.abs().max()) < 1e3, n
+        if n.endswith("qkv.bias"):
+            # the key third of this bias has a mathematically zero gradient (softmax is invariant to a per-query constant):
+            # what arrives is rounding noise, AdamW normalises it to +-lr steps, and eager and replayed runs (fp32 atomics
+            # in another order) walk different random paths there
+            continue
+        assert rel_l2(p2, p1) < 2e-3, (n, rel_l2(p2, p1))
+        assert rel_l2(p2.grad, p1.grad) < 2e-2, (n, rel_l2(p2.grad, p1.grad))       # the last step's gradients
+    for g1, g2 in zip(o1.groups, o2.groups):
+        for key in ("m", "v"):
+            assert bool(torch.isfinite(g2[key]).all()), key
+            assert rel_l2(g2[key], g1[key]) < 2e-2, (key, rel_l2(g2[key], g1[key]))
+        assert float(g2["v"].max()) < 1e3
+
+
 def test_graphed_step_with_dropout_matches_eager_steps(favit, monkeypatch):
     """The reference's training setting (dropout = attn_dropout = embed_dropout = 0.1, main.py:106) through
     train.GraphedStep: dropout seeds are frozen into the captured kernels, a device epoch word (bumped by the graph's
