@@ -57,9 +57,11 @@ _SIGS = {
     "favit_set_health_word": ([vp], C.c_int),
     "favit_gemm": ([C.POINTER(GemmDesc), vp], C.c_int),
     "favit_gemm_last_kernel": ([], C.c_char_p),
+    "favit_ln_gemm": ([C.POINTER(GemmDesc), vp, i64, vp, vp, f32, vp, vp, vp, vp], C.c_int),
     "favit_gemm_grouped_tn": ([C.POINTER(GemmDesc), i32, vp], C.c_int),
     "favit_gemm_grouped_tn_workspace": ([C.POINTER(GemmDesc), i32], C.c_int64),
     "favit_gemm_grouped_tn_ws": ([C.POINTER(GemmDesc), i32, vp, i64, vp], C.c_int),
+    "favit_gemm_grouped_last_splits": ([], C.c_int),
     "favit_cast": ([vp, C.c_int, vp, C.c_int, i64, vp], C.c_int),
     "favit_fp8_amax": ([vp, C.c_int, i64, i64, i64, vp, vp], C.c_int),
     "favit_fp8_quantize": ([vp, C.c_int, i64, i64, i64, vp, i64, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp], C.c_int),

@@ -30,6 +30,7 @@ namespace {
 // name of the kernel family the last favit_gemm / grouped launch of this host thread dispatched to
 // (favit_gemm_last_kernel: tests and bench.py read it to assert / report which kernel really ran)
 thread_local const char* g_last_kernel = "none";
+thread_local int g_last_grouped_splits = 0;   // K-splits the last grouped weight-gradient launch of this thread used
 
 constexpr int BM = 128;
 constexpr int BN = 128;
@@ -938,10 +939,14 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
   unsigned long long tl0 = 0, tl1 = 0;
   if (tl) tl0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0) && (wc == 0);
-  f32x4 racc[4];
+  // fused bias gradient (row sums of the mn-major A operand) by one extra ones-MFMA per A fragment.  The two waves of
+  // a row (wc = 0 / 1) hold the SAME four A fragments: each takes two of them (round 4: eight accumulator registers
+  // per wave instead of sixteen in every other wave -- with sixteen the allocator spilled them inside the K loop of
+  // the grouped kernel, and the reload's vmcnt(0) drained the DMA ring every k-step: 233 -> 306 us per cfg2 block).
+  const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0);
+  f32x4 racc[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) racc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 2; ++i) racc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   bf16x8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
@@ -1042,17 +1047,22 @@ __device__ __forceinline__ void p4_body(const KParams& p, int tile, int split, i
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = mfma_tile<F8>(bfr[j], af[i], acc[i][j]);
     if (F8 == 0 && do_rowsum) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) racc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], racc[i], 0, 0, 0);
+      if (wc) {                                  // (wave-uniform)
+        racc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[2], racc[0], 0, 0, 0);
+        racc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[3], racc[1], 0, 0, 0);
+      } else {
+        racc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[0], racc[0], 0, 0, 0);
+        racc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[1], racc[1], 0, 0, 0);
+      }
     }
     cur = cur == 2 ? 0 : cur + 1;
   }
   if (F8 == 0 && do_rowsum && lane < 16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long m = m0 + wr * 64 + i * 16 + lane;
+    for (int i = 0; i < 2; ++i) {
+      const long m = m0 + wr * 64 + (2 * wc + i) * 16 + lane;
       if (m < p.M) {
-        if (p.rowsum_store) p.a_rowsum[m] = racc[i][0];       // exactly one tile column (n0 == 0) writes row m
+        if (p.rowsum_store) p.a_rowsum[m] = racc[i][0];       // exactly one wave of one tile column (n0 == 0) writes row m
         else atomicAdd(p.a_rowsum + m, racc[i][0]);
       }
     }
@@ -1614,55 +1624,263 @@ int launch_s64(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
   return FAVIT_OK;
 }
 
-// Grouped weight-gradient launch: several dW = dY^T.X problems that share the token dimension (the
-// four Linear layers of one transformer block) run as ONE grid.  Their tiles together fill the 64
-// workgroup slots of an XCD with a single K-split per XCD (8 splits in all instead of 24 each), which
-// cuts the fp32-atomic traffic of the split-K reduction ~3x and keeps every split's token rows in
-// one XCD's L2.
-constexpr int GROUP_MAX = 8;
-struct GroupParams {
-  int count, total_tiles, nsplit, pad_;
-  long slab_stride;    // floats between the partial-result slabs of consecutive K-splits (0: fp32 atomics into C)
-  int tile_off[GROUP_MAX + 1];
-  KParams p[GROUP_MAX];
+// --------------------------------------------------------------------------------------
+// bf16 kernel "s64ln": LayerNorm fused into the A-operand staging of the 64x128-tile kernel, for the short-token
+// configurations (17 / 65 tokens per image: a block's forward is seven launches of 5-15 us, two of them the LayerNorms
+// in front of the qkv and fc1 projections).  The workgroup reads its 64 rows of the fp32 residual stream, normalises
+// them (two-pass mean / variance as csrc/norm_elem.hip, 16 lanes per row, reductions in the VALU by DPP) and writes
+// the bf16 result as the WHOLE-K A panel into LDS in the stage images the fragment reads expect (K = D <= 512); only
+// the weight tiles go through the DMA ring (three 16-KiB stages; two for D > 256 so that two workgroups still share a
+// CU).  The workgroup of tile column 0 also writes xn / mean / rstd for backward (the weight-gradient launch reads xn).
+// Every column tile of a row block recomputes the normalisation (9-12x 98 KB from L2): cheaper than one more launch.
+// --------------------------------------------------------------------------------------
+struct LnFuse {
+  const float* x;        // fp32 residual stream, rows of ldx
+  long ldx;
+  const float* gamma;
+  const float* beta;
+  bf16_t* xn;            // [M, D] bf16 out (saved for backward)
+  float* mean;
+  float* rstd;
+  float eps;
 };
 
-__global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_grouped_tn_kernel(GroupParams gp) {
-  const int h = blockIdx.x, xcd = h & 7, idx = h >> 3;
-  const int split = xcd + 8 * (idx / gp.total_tiles);
-  const int t = idx % gp.total_tiles;
-  int i = 0;
-  while (i + 1 < gp.count && t >= gp.tile_off[i + 1]) ++i;
-  if (gp.slab_stride == 0) {
-    p4_body<false, false, float>(gp.p[i], t - gp.tile_off[i], split, 0);
-  } else {
-    // slab mode: this split's partial tile goes to its own slab with plain 16-byte stores (no atomics)
-    KParams kp = gp.p[i];
-    kp.C = reinterpret_cast<float*>(kp.C) + (long)split * gp.slab_stride;
-    if (kp.a_rowsum) kp.a_rowsum += (long)split * gp.slab_stride;
-    p4_body<false, false, float>(kp, t - gp.tile_off[i], split, 0);
+__device__ __forceinline__ float dpp_sum16(float v) {
+  v = dpp_sum8(v);
+  // row_mirror (0x140): lane i <- lane 15 - i of its row of 16: the other half's sum of eight
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+}
+
+template <typename OutT, int NI, int NSTB>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_s64ln_kernel(KParams p, LnFuse q) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* panel = smem;                                   // NI stage images of the A operand: [64 rows][64 k] bf16
+  char* ring = smem + NI * S64_A_BYTES;                 // NSTB stages of the B operand: [128 rows][64 k]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long m0 = (long)(tile / p.tiles_n) * S64_BM;
+  const long n0 = (long)(tile % p.tiles_n) * BN;
+  const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B);
+  OutT* C = reinterpret_cast<OutT*>(p.C);
+  constexpr int D = NI * 64;
+
+  const bf16_t* sb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sb[j] = glds_src<true>(Bm, p.ldb, n0, p.N, 0, wave * 4 + j, lane);
+  auto issue = [&](int buf) {
+    char* st = ring + buf * OP16_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sb[j], (lptr_t)(st + (wave * 4 + j) * 1024), 16, 0, 0);
+      sb[j] += BK16;
+    }
+  };
+  issue(0);                                              // the weight stream starts under the LayerNorm
+  if (NSTB == 3 && NI > 1) issue(1);
+
+  // ---- LayerNorm of rows m0 .. m0 + 63: wave w owns rows 16 w .. 16 w + 15, four at a time, 16 lanes per row ----
+  const int j16 = lane & 15, rsub = lane >> 4;
+  const bool write_xn = (n0 == 0) && q.xn != nullptr;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int r = wave * 16 + it * 4 + rsub;
+    long m = m0 + r;
+    const bool live = m < p.M;
+    if (!live) m = p.M - 1;                              // rows past M: a valid row, never stored
+    const float* xr = q.x + m * q.ldx;
+    float4 v[NI];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      v[i] = *reinterpret_cast<const float4*>(xr + 4 * (j16 + 16 * i));
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mu = dpp_sum16(s) * (1.0f / (float)D);
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+      qq += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rs = rsqrtf(dpp_sum16(qq) * (1.0f / (float)D) + q.eps);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 4 * (j16 + 16 * i);
+      const float4 g = *reinterpret_cast<const float4*>(q.gamma + col);
+      const float4 be = *reinterpret_cast<const float4*>(q.beta + col);
+      bf16x4 o;
+      o[0] = (bf16_t)((v[i].x - mu) * rs * g.x + be.x);
+      o[1] = (bf16_t)((v[i].y - mu) * rs * g.y + be.y);
+      o[2] = (bf16_t)((v[i].z - mu) * rs * g.z + be.z);
+      o[3] = (bf16_t)((v[i].w - mu) * rs * g.w + be.w);
+      // stage image i (k = 64 i .. 64 i + 63): 128-byte rows, 16-byte chunk kc at kc ^ ((row >> 1) & 7) (load_frag16)
+      *reinterpret_cast<bf16x4*>(panel + i * S64_A_BYTES + r * 128 + ((((j16 >> 1)) ^ ((r >> 1) & 7)) << 4) + (j16 & 1) * 8) = o;
+      if (write_xn && live) *reinterpret_cast<bf16x4*>(q.xn + m * (long)D + col) = o;
+    }
+    if (write_xn && live && j16 == 0) {
+      q.mean[m] = mu;
+      q.rstd[m] = rs;
+    }
   }
+  __syncthreads();        // the A panel is complete (and: this wave's loads and stores so far have all returned)
+
+  f32x4 acc[4][4];                        // rows 0..31 of the wave tile live in acc[0..1][*]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+#pragma unroll
+  for (int kt = 0; kt < NI; ++kt) {
+    if (NSTB == 3 && kt + 1 < NI) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (NSTB == 3) { if (kt + 2 < NI) issue(cur >= 1 ? cur - 1 : 2); }
+    else if (kt + 1 < NI) issue(cur ^ 1);
+    const char* la = panel + kt * S64_A_BYTES;
+    const char* lb = ring + cur * OP16_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[2], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = load_frag16<true>(la, wr * 32 + i * 16, ks, lane);
+      load_frags4<true, false>(lb, wc * 64, ks, lane, bfr);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    cur = NSTB == 3 ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
+  }
+  __syncthreads();        // every wave is done with panel and ring; LDS becomes wave-private scratch
+  wave_epilogue_rows<bf16_t, OutT, 0, 2>(p, acc, C, m0 + wr * 32, n0 + wc * 64, lane,
+                                         reinterpret_cast<float*>(smem + wave * WEPI_BYTES), true, p.alpha);
+}
+
+// Grouped weight-gradient launch: up to GROUP_MAX dW = dY^T.X problems that share the token dimension (the four
+// Linear layers of one transformer block -- or, since round 4, of SEVERAL blocks: functional.flush_wgrads collects the
+// problems of up to four blocks, or of the whole encoder at short token counts) run as ONE grid.
+//   * chunk = consecutive problems with at most 64 tiles together (one block's four problems at D = 384: 63 tiles =
+//     the 64 workgroup slots of an XCD);  unit = (chunk, K-split);  every unit is pinned to ONE XCD (host-side
+//     longest-first packing into eight queues), so the tiles that stream the same token rows share that XCD's L2;
+//   * the number of K-splits is the minimum of a cost model (grouped_plan): rounds x (k-steps + fixed) + slab traffic.
+//     More blocks per launch need fewer splits to fill the chip -- four cfg2 blocks: 2 splits instead of 8, a quarter
+//     of the slab bytes and of the prologue / epilogue / reduction launches per flop; twelve cfg3 blocks: NO split at
+//     all (no slabs, no reduction kernel, the result is one rounding of one fp32 accumulation chain);
+//   * nsplit > 1: partial tiles go to per-split slabs with plain stores and grouped_reduce_kernel adds the slabs in
+//     split order (deterministic; no fp32 atomics);  nsplit == 1: the tile epilogue writes dW itself (reading the
+//     previous value when the problem accumulates).
+constexpr int GROUP_MAX = 48;
+constexpr int GROUP_XCD_UNITS = 24;     // units in one XCD's queue, at most
+struct TnProb {          // 64 bytes
+  const void* A;         // dY [T, M], mn-major
+  const void* B;         // X  [T, N], mn-major
+  float* C;              // dW, or the problem's place in slab 0
+  float* rowsum;         // db, or its place in slab 0 (null: no bias gradient)
+  int M, N, lda, ldb, ldc, tiles_n, ntiles;
+  int flags;             // 1: the direct epilogue adds the previous value of C (accumulate, nsplit == 1); 2: C / ldc allow 16-byte stores
+};
+struct GroupParams {
+  int count, nchunks, nsplit, mode;       // mode 0: fp32 atomics into C, 1: slabs, 2: direct (nsplit == 1)
+  long slab_stride;                        // floats between the slabs of consecutive K-splits
+  long k_per_split, K;
+  unsigned short chunk_tiles[GROUP_MAX];
+  unsigned char chunk_first[GROUP_MAX + 1];
+  unsigned char xcd_count[8];
+  unsigned char xcd_units[8][GROUP_XCD_UNITS];   // unit = split * nchunks + chunk
+  TnProb p[GROUP_MAX];
+};
+static_assert(sizeof(GroupParams) <= 4000, "kernel arguments are limited to 4 KiB");
+
+__global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_grouped_tn_kernel(GroupParams gp) {
+  const int h = blockIdx.x, xcd = h & 7;
+  int idx = h >> 3;
+  // this XCD's queue of units, in order: find the unit and the tile inside its chunk (workgroup-uniform scalars)
+  const int nu = gp.xcd_count[xcd];
+  int j = 0, c = 0, split = 0;
+  for (;; ++j) {
+    if (j >= nu) return;                       // this XCD's queue is shorter than the longest one (whole workgroup leaves)
+    const int u = gp.xcd_units[xcd][j];
+    c = u % gp.nchunks;
+    split = u / gp.nchunks;
+    const int tiles = gp.chunk_tiles[c];
+    if (idx < tiles) break;
+    idx -= tiles;
+  }
+  int i = gp.chunk_first[c];
+  while (idx >= gp.p[i].ntiles) { idx -= gp.p[i].ntiles; ++i; }
+  i = __builtin_amdgcn_readfirstlane(i);              // (all of this is workgroup-uniform: keep it in SGPRs)
+  idx = __builtin_amdgcn_readfirstlane(idx);
+  split = __builtin_amdgcn_readfirstlane(split);
+  const TnProb& q = gp.p[i];
+  KParams kp = {};
+  kp.A = q.A; kp.B = q.B;
+  kp.M = q.M; kp.N = q.N; kp.K = gp.K;
+  kp.lda = q.lda; kp.ldb = q.ldb; kp.ldc = q.ldc;
+  kp.k_per_split = gp.k_per_split;
+  kp.batch_inner = 1;
+  kp.a_vec = kp.b_vec = 1;
+  kp.tiles_n = q.tiles_n; kp.ntiles = q.ntiles;
+  kp.alpha = 1.0f; kp.drop_scale = 1.0f;
+  kp.xcd_split = 1;
+  if (gp.mode == 1) {
+    // slab mode: this split's partial tile goes to its own slab with plain 16-byte stores (no atomics)
+    kp.C = q.C + (long)split * gp.slab_stride;
+    kp.a_rowsum = q.rowsum ? q.rowsum + (long)split * gp.slab_stride : nullptr;
+    kp.c_vec = 1;
+    kp.rowsum_store = 1;
+  } else if (gp.mode == 2) {
+    // one split: the epilogue writes dW itself; an accumulating problem reads the previous value as a residual.
+    // The bias gradient is ADDED to its destination by contract: one fp32 atomic per row (a single addend: exact)
+    kp.C = q.C;
+    kp.a_rowsum = q.rowsum;
+    kp.c_vec = (q.flags & 2) ? 1 : 0;
+    if (q.flags & 1) { kp.residual = q.C; kp.ld_res = q.ldc; }
+  } else {
+    kp.C = q.C;
+    kp.a_rowsum = q.rowsum;
+    kp.atomic = 1;
+  }
+#ifdef FAVIT_PROBE
+  kp.dbg = gp.count < 0 ? 1 : 0;          // (host: FAVIT_GEMM_DBG=1)
+#endif
+  p4_body<false, false, float>(kp, idx, split, 0);
 }
 
 // Second half of the slab-mode split-K: dst = (accumulate ? dst : 0) + sum over the splits' slabs, in split order
 // (a fixed summation order: weight gradients are bitwise reproducible, unlike fp32 atomics).
-struct ReduceSeg {
-  float* dst;          // dW [rows, ld] or db [rows]
-  long off;            // offset of this segment inside a slab (floats)
-  long rows, cols, ld; // cols = 1, ld = 1 for a bias-gradient segment
+struct ReduceSeg {       // 32 bytes
+  float* dst;            // dW [rows, ld] or db [rows]
+  long off;              // offset of this segment inside a slab (floats)
+  int rows, cols, ld;    // cols = the vector's length, rows = 1, ld = cols for a bias-gradient segment
   int accumulate;
 };
 struct ReduceParams {
   const float* ws;
   long slab_stride;
   int nsplit, nseg;
+  int blk_off[2 * GROUP_MAX + 1];   // first workgroup of every segment (a segment gets one workgroup per 2048 floats)
   ReduceSeg seg[2 * GROUP_MAX];
 };
+static_assert(sizeof(ReduceParams) <= 4000, "kernel arguments are limited to 4 KiB");
+constexpr int REDUCE_PER_BLOCK = 2;     // float4 per thread
 
 __global__ __launch_bounds__(256) void grouped_reduce_kernel(ReduceParams rp) {
-  const ReduceSeg& sg = rp.seg[blockIdx.y];
-  const long n4 = sg.rows * sg.cols / 4;               // rows * cols is a multiple of 4 (host)
-  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+  int lo = 0, hi = rp.nseg - 1;         // segment of this workgroup (uniform binary search over <= 96 entries)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)blockIdx.x >= rp.blk_off[mid]) lo = mid; else hi = mid - 1;
+  }
+  const ReduceSeg& sg = rp.seg[lo];
+  const long n4 = (long)sg.rows * sg.cols / 4;               // rows * cols is a multiple of 4 (host)
+  const long q0 = (long)((int)blockIdx.x - rp.blk_off[lo]) * (256 * REDUCE_PER_BLOCK) + threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < REDUCE_PER_BLOCK; ++it) {
+    const long q = q0 + it * 256;
+    if (q >= n4) break;
     const long e = 4 * q;
     const float* src = rp.ws + sg.off + e;
     // slabs in groups of eight: the loads of a group are all in flight before the first add (with one load per
@@ -1681,7 +1899,7 @@ __global__ __launch_bounds__(256) void grouped_reduce_kernel(ReduceParams rp) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
-    if (sidx + 6 < rp.nsplit) {                         // 7 left (8 splits: the common short-token case)
+    if (sidx + 6 < rp.nsplit) {                         // 7 left (8 splits)
       float4 v[7];
 #pragma unroll
       for (int u = 0; u < 7; ++u) v[u] = *reinterpret_cast<const float4*>(src + (long)(sidx + u) * rp.slab_stride);
@@ -2221,42 +2439,121 @@ long grouped_slab_floats(const favit_gemm_t* gs, int count) {
   return (tot + 63) / 64 * 64;
 }
 
-// splits = 8*s: one group of s splits per XCD.  The s <= 4 that minimises a two-term cost per output element among
-// those that leave every split at least one K-step (short token counts: fewer splits, not a refusal):
-//   main loops  2 K / (util(s) * 1.0 PF)      util = how full the last round of an XCD's 64 workgroup slots is
-//   slabs       8 s * 4 B * 2 / 4 TB/s        written by the tiles' epilogues, read back by the reduction
-// Round 2 maximised util alone and took 16 splits at ViT-Base (216 tiles: util 0.96 against 0.84): 453 MB of slabs per
-// block written and re-read instead of 227 -- cfg4 29.9 ms per step against 28.7 with 8 (and 31.3 / 32.7 with 24 / 32).
-// Returns 0 if even 8 splits do not fit.
-long grouped_nsplit(long total_tiles, long K, long* kps_out) {
+// FAVIT_GROUPED_S=n (A/B measurements): force n K-splits.  Read once per process.
+int grouped_forced_splits() {
+  static const int v = [] { const char* e = getenv("FAVIT_GROUPED_S"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
+// How a grouped launch is laid out: chunks (consecutive problems, <= 64 tiles), the number of K-splits and the
+// unit -> XCD queues.  The split count minimises
+//     max over XCDs of max(1, queue tiles / 64) x (k x 1.4 us x (1 + k / 4000) + 18 us)   k = 32-token k-steps per split
+//   + (nsplit > 1 ? (2 nsplit + 1) x output bytes / 5 TB/s + 5 us : 2 x output bytes / 5 TB/s)   slabs + reduction
+// among the split counts that keep a split at or below 6,400 tokens (when any does).  The constants are measured
+// (tools/grouped_probe.py, round 4, random data, back-to-back launches): 1.4 us per k-step of a round of 256x128
+// tiles with two workgroups per CU and ~18 us of prologue + epilogue per round (228 us for 2 rounds x 68 k-steps at
+// cfg3); the k / 4000 term is the DRIFT of long splits -- the 63 tiles of a unit stop sharing operand lines in their
+// XCD's L2 as they run apart: four cfg2 blocks in one launch took 1.60 us per k-step with 2 splits of 788 k-steps
+// against 1.37 with 8 splits of 197 (1300 vs 1214 us), which is also why the 6,400-token cap exists.  Round 2
+// maximised slot utilisation alone and took 16 splits at ViT-Base; round 3 priced the slabs; round 4 adds the
+// multi-block launches, where one or two splits fill the chip at short token counts (cfg3: 12 blocks, no split, no
+// slabs, no reduction kernel: 19 us per block against 40).
+struct GroupPlan {
+  int nchunks;
+  int chunk_first[GROUP_MAX + 1];
+  int chunk_tiles[GROUP_MAX];
+  long nsplit, kps;
+  int xcd_count[8];
+  int xcd_units[8][GROUP_XCD_UNITS];
+  long max_queue_tiles;
+};
+
+bool grouped_pack(GroupPlan& pl, long nsplit) {
+  // longest-first packing of the units into eight queues (units of one chunk are equal: walk chunks by size)
+  const int nunits = pl.nchunks * (int)nsplit;
+  if (nunits > 255 || nunits > 8 * GROUP_XCD_UNITS) return false;
+  int order[GROUP_MAX];
+  for (int c = 0; c < pl.nchunks; ++c) order[c] = c;
+  for (int a = 1; a < pl.nchunks; ++a)            // insertion sort, descending tiles (stable)
+    for (int b = a; b > 0 && pl.chunk_tiles[order[b]] > pl.chunk_tiles[order[b - 1]]; --b) { int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+  long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int x = 0; x < 8; ++x) pl.xcd_count[x] = 0;
+  for (int oc = 0; oc < pl.nchunks; ++oc) {
+    const int c = order[oc];
+    for (long sp = 0; sp < nsplit; ++sp) {
+      int best = -1;
+      for (int x = 0; x < 8; ++x)
+        if (pl.xcd_count[x] < GROUP_XCD_UNITS && (best < 0 || load[x] < load[best])) best = x;
+      if (best < 0) return false;
+      pl.xcd_units[best][pl.xcd_count[best]++] = (int)(sp * pl.nchunks + c);
+      load[best] += pl.chunk_tiles[c];
+    }
+  }
+  pl.max_queue_tiles = 0;
+  for (int x = 0; x < 8; ++x) pl.max_queue_tiles = load[x] > pl.max_queue_tiles ? load[x] : pl.max_queue_tiles;
+  return true;
+}
+
+// Returns false if the problems cannot be grouped (more than GROUP_MAX chunks cannot happen: a chunk holds >= 1 problem).
+bool grouped_plan(const favit_gemm_t* gs, int count, GroupPlan& pl) {
+  const long K = gs[0].K;
+  pl.nchunks = 0;
+  long out_floats = 0;
+  int cur = 0;
+  for (int i = 0; i < count; ++i) {
+    const long t = ((gs[i].M + P4_BM - 1) / P4_BM) * ((gs[i].N + BN - 1) / BN);
+    if (t > 65535) return false;
+    out_floats += gs[i].M * gs[i].N;
+    if (pl.nchunks == 0 || cur + t > 64) {
+      pl.chunk_first[pl.nchunks] = i;
+      pl.chunk_tiles[pl.nchunks] = 0;
+      ++pl.nchunks;
+      cur = 0;
+    }
+    cur += (int)t;
+    pl.chunk_tiles[pl.nchunks - 1] = cur;
+  }
+  pl.chunk_first[pl.nchunks] = count;
+  static const long cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+  const int forced = grouped_forced_splits();
   double best = 0.0;
   long best_s = 0, best_kps = 0;
-  long s_lo = 1, s_hi = 4;
-  { const char* e = getenv("FAVIT_GROUPED_S"); if (e && atoi(e) >= 1 && atoi(e) <= 4) s_lo = s_hi = atoi(e); }   // A/B: force 8 * s splits
-  for (long s = s_lo; s <= s_hi; ++s) {
-    const long nsplit = 8 * s;
-    long kps = (K + nsplit - 1) / nsplit;
+  constexpr long KPS_CAP = 6400;
+  bool best_capped = false;
+  for (long s0 : cand) {
+    const long s = forced > 0 ? (long)forced : s0;
+    long kps = (K + s - 1) / s;
     kps = ((kps + P4_BK - 1) / P4_BK) * P4_BK;
-    if ((nsplit - 1) * kps >= K) continue;            // the last split would be empty
-    const long w = total_tiles * s;
-    const double util = (double)w / (double)(((w + 63) / 64) * 64);
-    const double cost = 2.0 * (double)K / (util * 1.0e15) + 64.0 * (double)s / 4.0e12;
-    if (best_s == 0 || cost < best) { best = cost; best_s = s; best_kps = kps; }
+    if (s > 1 && (s - 1) * kps >= K) continue;        // the last split would be empty
+    GroupPlan trial = pl;
+    if (!grouped_pack(trial, s)) continue;
+    // (tiles of a queue do not run in strict rounds: 216 tiles on 64 slots take ~3.4 tile times, not 4)
+    const double rounds = trial.max_queue_tiles <= 64 ? 1.0 : (double)trial.max_queue_tiles / 64.0;
+    const double out_bytes = 4.0 * (double)out_floats;
+    const double ksteps = (double)(kps / P4_BK);
+    const double cost = rounds * (ksteps * 1.4e-6 * (1.0 + ksteps / 4000.0) + 18.0e-6) +
+                        (s > 1 ? (2.0 * (double)s + 1.0) * out_bytes / 5.0e12 + 5.0e-6 : 2.0 * out_bytes / 5.0e12);
+    const bool capped = kps <= KPS_CAP;               // a candidate under the cap beats any candidate over it
+    if (best_s == 0 || (capped && !best_capped) || (capped == best_capped && cost < best)) {
+      best = cost; best_s = s; best_kps = kps; best_capped = capped;
+    }
+    if (forced > 0) break;
   }
-  if (kps_out) *kps_out = best_kps;
-  return 8 * best_s;
+  if (best_s == 0) return false;
+  pl.nsplit = best_s;
+  pl.kps = best_kps;
+  return grouped_pack(pl, best_s);
 }
 
 int grouped_tn_impl(const favit_gemm_t* gs, int32_t count, float* ws, int64_t ws_bytes, void* stream) {
   if (!gs || count <= 0 || count > GROUP_MAX) return FAVIT_ERR_INVALID;
   hipStream_t st = as_stream(stream);
   GroupParams gp;
-  memset(&gp, 0, sizeof(gp));          // every field of every KParams defined, whatever is added to the struct later
+  memset(&gp, 0, sizeof(gp));          // every field defined, whatever is added to the structs later
   gp.count = count;
-  gp.pad_ = 0;
   const long K = gs[0].K;
   if (K <= 0 || (K % P4_BK) != 0) return FAVIT_ERR_UNSUPPORTED;
-  int off = 0;
+  bool direct_ok = true;               // nsplit == 1 needs nothing; 16-byte stores when C allows them
   for (int i = 0; i < count; ++i) {
     const favit_gemm_t* g = gs + i;
     if (!g->A || !g->B || !g->C || g->M <= 0 || g->N <= 0) return FAVIT_ERR_INVALID;
@@ -2265,49 +2562,35 @@ int grouped_tn_impl(const favit_gemm_t* gs, int32_t count, float* ws, int64_t ws
         g->dropout_p > 0.f || g->alpha != 1.0f)
       return FAVIT_ERR_UNSUPPORTED;
     if (!aligned(g->A, 16) || !aligned(g->B, 16) || (g->lda % 8) || (g->ldb % 8) || (g->M % 8) || (g->N % 8) ||
-        g->M < 8 || g->N < 8)
+        g->M < 8 || g->N < 8 || g->lda > INT32_MAX || g->ldb > INT32_MAX || g->ldc > INT32_MAX || g->M > INT32_MAX ||
+        g->N > INT32_MAX)
       return FAVIT_ERR_UNSUPPORTED;
-    KParams& kp = gp.p[i];
-    kp.A = g->A; kp.B = g->B; kp.C = g->C;
-    kp.bias = nullptr; kp.aux_in = nullptr; kp.aux_out = nullptr; kp.residual = nullptr;
-    kp.a_rowsum = g->a_rowsum;
-    kp.M = g->M; kp.N = g->N; kp.K = K;
-    kp.lda = g->lda; kp.ldb = g->ldb; kp.ldc = g->ldc;
-    kp.ld_aux_in = kp.ld_aux_out = kp.ld_res = 0;
-    kp.sAo = kp.sAi = kp.sBo = kp.sBi = kp.sCo = kp.sCi = 0;
-    kp.batch_inner = 1;
-    kp.act = FAVIT_ACT_NONE;
-    kp.atomic = 1;
-    kp.a_vec = kp.b_vec = 1;
-    kp.c_vec = 0;
-    kp.tiles_n = (int)((g->N + BN - 1) / BN);
-    kp.ntiles = (int)(((g->M + P4_BM - 1) / P4_BM) * kp.tiles_n);
-    kp.xcd_split = 1;
-    kp.alpha = 1.0f;
-    kp.drop_thresh = 0; kp.drop_scale = 1.0f; kp.drop_seed = 0; kp.drop_epoch = nullptr;
-    kp.store_policy = 0;
-    kp.rowsum_store = 0;
-    kp.q_block0 = kp.q_tile0 = 0;
-      kp.scale_a = kp.scale_b = nullptr;
-#ifdef FAVIT_PROBE
-    kp.dbg = knobs().dbg;            // probe build: FAVIT_GEMM_DBG=1 times the grouped main loop without its epilogue
-    kp.probe = nullptr;
-#endif
-    gp.tile_off[i] = off;
-    off += kp.ntiles;
+    TnProb& q = gp.p[i];
+    q.A = g->A; q.B = g->B; q.C = reinterpret_cast<float*>(g->C); q.rowsum = g->a_rowsum;
+    q.M = (int)g->M; q.N = (int)g->N; q.lda = (int)g->lda; q.ldb = (int)g->ldb; q.ldc = (int)g->ldc;
+    q.tiles_n = (int)((g->N + BN - 1) / BN);
+    q.ntiles = (int)(((g->M + P4_BM - 1) / P4_BM) * q.tiles_n);
+    q.flags = (g->accumulate ? 1 : 0) | (((g->ldc % 4) == 0 && aligned(g->C, 16)) ? 2 : 0);
   }
-  gp.tile_off[count] = off;
-  gp.total_tiles = off;
-  long kps = 0;
-  const long nsplit = grouped_nsplit(off, K, &kps);
-  if (nsplit == 0) return FAVIT_ERR_UNSUPPORTED;                    // too few tokens to split 8 ways
-  gp.nsplit = (int)nsplit;
-  for (int i = 0; i < count; ++i) gp.p[i].k_per_split = kps;
-
   const long stride = grouped_slab_floats(gs, count);
-  bool slabs = ws != nullptr && ws_bytes >= (int64_t)(nsplit * stride * 4) && aligned(ws, 16);
+  bool slab_dst_ok = ws != nullptr && aligned(ws, 16);
   for (int i = 0; i < count; ++i)      // the reduction writes 16-byte vectors: unaligned destinations keep the atomic path
-    slabs = slabs && (gs[i].ldc % 4) == 0 && aligned(gs[i].C, 16) && (!gs[i].a_rowsum || aligned(gs[i].a_rowsum, 16));
+    slab_dst_ok = slab_dst_ok && (gs[i].ldc % 4) == 0 && aligned(gs[i].C, 16) && (!gs[i].a_rowsum || aligned(gs[i].a_rowsum, 16));
+  GroupPlan pl;
+  if (!grouped_plan(gs, count, pl)) return FAVIT_ERR_UNSUPPORTED;
+  const long nsplit = pl.nsplit;
+  gp.nsplit = (int)nsplit;
+  gp.k_per_split = pl.kps;
+  gp.K = K;
+  gp.nchunks = pl.nchunks;
+  for (int c = 0; c < pl.nchunks; ++c) { gp.chunk_tiles[c] = (unsigned short)pl.chunk_tiles[c]; gp.chunk_first[c] = (unsigned char)pl.chunk_first[c]; }
+  gp.chunk_first[pl.nchunks] = (unsigned char)count;
+  for (int x = 0; x < 8; ++x) {
+    gp.xcd_count[x] = (unsigned char)pl.xcd_count[x];
+    for (int j = 0; j < pl.xcd_count[x]; ++j) gp.xcd_units[x][j] = (unsigned char)pl.xcd_units[x][j];
+  }
+  const bool slabs = nsplit > 1 && slab_dst_ok && ws_bytes >= (int64_t)(nsplit * stride * 4);
+  gp.mode = nsplit == 1 ? 2 : (slabs ? 1 : 0);
   gp.slab_stride = slabs ? stride : 0;
   ReduceParams rp;
   if (slabs) {
@@ -2315,25 +2598,30 @@ int grouped_tn_impl(const favit_gemm_t* gs, int32_t count, float* ws, int64_t ws
     // slabs in split order.  fp32 atomics reach ~1.3 TB/s chip-wide (MI355X_MICROARCH.md) against ~5 TB/s for plain
     // stores + the reduction's reads: measured 318 -> 227 us main loop + epilogue at the cfg2 block shapes and
     // 914 -> 538 us at ViT-Base (tools/grouped_probe.py), and the result no longer depends on arrival order.
+    memset(&rp, 0, sizeof(rp));
     rp.ws = ws; rp.slab_stride = stride; rp.nsplit = (int)nsplit; rp.nseg = 0;
     long o = 0;
+    int blk = 0;
+    auto add_seg = [&](float* dst, long off, long rows, long cols, long ld, int acc) {
+      rp.seg[rp.nseg] = ReduceSeg{dst, off, (int)rows, (int)cols, (int)ld, acc};
+      rp.blk_off[rp.nseg++] = blk;
+      blk += (int)((rows * cols / 4 + 256 * REDUCE_PER_BLOCK - 1) / (256 * REDUCE_PER_BLOCK));
+    };
     for (int i = 0; i < count; ++i) {
-      KParams& kp = gp.p[i];
-      rp.seg[rp.nseg++] = ReduceSeg{reinterpret_cast<float*>(gs[i].C), o, gs[i].M, gs[i].N, gs[i].ldc, gs[i].accumulate ? 1 : 0};
-      kp.C = ws + o;
-      kp.ldc = gs[i].N;
-      kp.atomic = 0;
-      kp.c_vec = 1;
+      TnProb& q = gp.p[i];
+      add_seg(reinterpret_cast<float*>(gs[i].C), o, gs[i].M, gs[i].N, gs[i].ldc, gs[i].accumulate ? 1 : 0);
+      q.C = ws + o;
+      q.ldc = (int)gs[i].N;
       o += gs[i].M * gs[i].N;
       if (gs[i].a_rowsum) {
         // the bias gradient is always ADDED to its destination (the fused column sum's contract); M % 8 == 0
-        rp.seg[rp.nseg++] = ReduceSeg{gs[i].a_rowsum, o, 1, gs[i].M, gs[i].M, 1};
-        kp.a_rowsum = ws + o;
-        kp.rowsum_store = 1;
+        add_seg(gs[i].a_rowsum, o, 1, gs[i].M, gs[i].M, 1);
+        q.rowsum = ws + o;
       }
       o += ((gs[i].M + 3) / 4) * 4;
     }
-  } else {
+    rp.blk_off[rp.nseg] = blk;
+  } else if (gp.mode == 0) {
     for (int i = 0; i < count; ++i) {
       if (!gs[i].accumulate) {
         const long total = gs[i].M * gs[i].N;
@@ -2344,11 +2632,16 @@ int grouped_tn_impl(const favit_gemm_t* gs, int32_t count, float* ws, int64_t ws
       }
     }
   }
+#ifdef FAVIT_PROBE
+  if (knobs().dbg == 1) gp.count = -count;            // probe build: FAVIT_GEMM_DBG=1 times the grouped main loop without its epilogue
+#endif
+  g_last_kernel = "grouped_tn";
+  g_last_grouped_splits = (int)nsplit;
   favit_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_p4_grouped_tn_kernel), P4_LDS);
-  hipLaunchKernelGGL(gemm_bf16_p4_grouped_tn_kernel, dim3((unsigned)(off * nsplit)), dim3(P4_THREADS), P4_LDS, st, gp);
+  hipLaunchKernelGGL(gemm_bf16_p4_grouped_tn_kernel, dim3((unsigned)(8 * pl.max_queue_tiles)), dim3(P4_THREADS), P4_LDS, st, gp);
   FAVIT_CHECK_LAUNCH();
   if (slabs) {
-    hipLaunchKernelGGL(grouped_reduce_kernel, dim3(512, (unsigned)rp.nseg), dim3(256), 0, st, rp);
+    hipLaunchKernelGGL(grouped_reduce_kernel, dim3((unsigned)rp.blk_off[rp.nseg]), dim3(256), 0, st, rp);
     FAVIT_CHECK_LAUNCH();
   }
   return FAVIT_OK;
@@ -2361,13 +2654,91 @@ extern "C" int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void
 }
 
 extern "C" int64_t favit_gemm_grouped_tn_workspace(const favit_gemm_t* gs, int32_t count) {
-  if (!gs || count <= 0 || count > GROUP_MAX) return 0;
-  long tiles = 0;
-  for (int i = 0; i < count; ++i) tiles += ((gs[i].M + P4_BM - 1) / P4_BM) * ((gs[i].N + BN - 1) / BN);
-  return (int64_t)(grouped_nsplit(tiles, gs[0].K, nullptr) * grouped_slab_floats(gs, count) * 4);
+  if (!gs || count <= 0 || count > GROUP_MAX || gs[0].K <= 0) return 0;
+  GroupPlan pl;
+  if (!grouped_plan(gs, count, pl)) return 0;
+  return pl.nsplit > 1 ? (int64_t)(pl.nsplit * grouped_slab_floats(gs, count) * 4) : 0;
 }
 
 extern "C" int favit_gemm_grouped_tn_ws(const favit_gemm_t* gs, int32_t count, void* workspace, int64_t workspace_bytes,
                                         void* stream) {
   return grouped_tn_impl(gs, count, reinterpret_cast<float*>(workspace), workspace_bytes, stream);
+}
+
+extern "C" int favit_gemm_grouped_last_splits(void) { return g_last_grouped_splits; }
+
+// LayerNorm + small-M forward GEMM in one launch (gemm_bf16_s64ln_kernel); see include/favit.h.
+extern "C" int favit_ln_gemm(const favit_gemm_t* g, const float* x, int64_t ldx, const float* gamma, const float* beta,
+                             float eps, void* xn, float* mean, float* rstd, void* stream) {
+  if (!g || !g->B || !g->C || !x || !gamma || !beta || !xn || !mean || !rstd) return FAVIT_ERR_INVALID;
+  if (g->M <= 0 || g->N <= 0 || g->K <= 0) return FAVIT_ERR_INVALID;
+  if (g->in_dtype != FAVIT_BF16 || !g->b_kmajor || g->batch > 1 || g->split_k > 1 || g->accumulate || g->a_rowsum)
+    return FAVIT_ERR_UNSUPPORTED;
+  if ((g->K % 64) != 0 || g->K > 512 || g->K == 320 || g->K == 448) return FAVIT_ERR_UNSUPPORTED;   // NI in {1,2,3,4,6,8}
+  if (g->act < FAVIT_ACT_NONE || g->act > FAVIT_ACT_MULAUX) return FAVIT_ERR_INVALID;
+  if ((g->act == FAVIT_ACT_DGELU || g->act == FAVIT_ACT_MULAUX) && !g->aux_in) return FAVIT_ERR_INVALID;
+  if (g->act == FAVIT_ACT_GELU_SAVEGRAD && !g->aux_out) return FAVIT_ERR_INVALID;
+  if (!aligned(g->B, 16) || (g->ldb % 8) != 0 || (ldx % 4) != 0 || !aligned(x, 16) || !aligned(gamma, 16) ||
+      !aligned(beta, 16) || !aligned(xn, 8))
+    return FAVIT_ERR_ALIGN;
+  if (g->dropout_p < 0.f || g->dropout_p >= 1.f) return FAVIT_ERR_INVALID;
+  const long tiles_n = (g->N + BN - 1) / BN, tm = (g->M + S64_BM - 1) / S64_BM;
+  // the regime of the 64-row kernel (favit_gemm: fewer than 1.5 128x128 tiles per CU); beyond it LayerNorm is a
+  // bandwidth-bound pass of its own and the large-tile kernels take the GEMM
+  if (((g->M + BM - 1) / BM) * tiles_n >= 384 || g->M <= 64) return FAVIT_ERR_UNSUPPORTED;
+  KParams kp;
+  memset(&kp, 0, sizeof(kp));
+  kp.B = g->B; kp.C = g->C;
+  kp.bias = g->bias; kp.aux_in = g->aux_in; kp.aux_out = g->aux_out; kp.residual = g->residual;
+  kp.M = g->M; kp.N = g->N; kp.K = g->K;
+  kp.ldb = g->ldb; kp.ldc = g->ldc;
+  kp.ld_aux_in = g->ld_aux_in; kp.ld_aux_out = g->ld_aux_out; kp.ld_res = g->ld_res;
+  kp.batch_inner = 1;
+  kp.act = g->act;
+  kp.tiles_n = (int)tiles_n;
+  kp.ntiles = (int)(tm * tiles_n);
+  kp.alpha = g->alpha;
+  kp.store_policy = knobs().store_policy;
+  kp.drop_thresh = dropout_threshold(g->dropout_p);
+  kp.drop_scale = 1.0f / (1.0f - g->dropout_p);
+  kp.drop_seed = g->dropout_seed;
+  kp.drop_epoch = favit_dropout_epoch_ptr_();
+  kp.a_vec = kp.b_vec = 1;
+  const size_t osz = g->out_dtype == FAVIT_BF16 ? 2 : 4;
+  bool cv = aligned(g->C, 4 * osz) && (g->ldc % 4) == 0;
+  if (g->bias) cv = cv && aligned(g->bias, 16);
+  if (g->aux_out) cv = cv && aligned(g->aux_out, 4 * osz) && (g->ld_aux_out % 4) == 0;
+  if (g->aux_in) cv = cv && aligned(g->aux_in, 8) && (g->ld_aux_in % 4) == 0;
+  if (g->residual) cv = cv && aligned(g->residual, 16) && (g->ld_res % 4) == 0;
+  kp.c_vec = cv ? 1 : 0;
+  LnFuse q{x, (long)ldx, gamma, beta, reinterpret_cast<bf16_t*>(xn), mean, rstd, eps};
+  const int ni = (int)(g->K / 64);
+  const int nstb = ni > 4 ? 2 : 3;
+  const int lds_bytes = ni * S64_A_BYTES + nstb * OP16_BYTES < 4 * WEPI_BYTES ? 4 * WEPI_BYTES : ni * S64_A_BYTES + nstb * OP16_BYTES;
+  const dim3 grid((unsigned)(tm * tiles_n));
+  hipStream_t st = as_stream(stream);
+  g_last_kernel = "s64ln";
+#define FAVIT_LNG(NI_, NSTB_)                                                                                          \
+  do {                                                                                                                 \
+    if (g->out_dtype == FAVIT_BF16) {                                                                                  \
+      favit_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_s64ln_kernel<bf16_t, NI_, NSTB_>), lds_bytes);      \
+      hipLaunchKernelGGL((gemm_bf16_s64ln_kernel<bf16_t, NI_, NSTB_>), grid, dim3(NTHREADS), lds_bytes, st, kp, q);    \
+    } else {                                                                                                           \
+      favit_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_s64ln_kernel<float, NI_, NSTB_>), lds_bytes);       \
+      hipLaunchKernelGGL((gemm_bf16_s64ln_kernel<float, NI_, NSTB_>), grid, dim3(NTHREADS), lds_bytes, st, kp, q);     \
+    }                                                                                                                  \
+  } while (0)
+  switch (ni) {
+    case 1: FAVIT_LNG(1, 3); break;
+    case 2: FAVIT_LNG(2, 3); break;
+    case 3: FAVIT_LNG(3, 3); break;
+    case 4: FAVIT_LNG(4, 3); break;
+    case 6: FAVIT_LNG(6, 2); break;
+    case 8: FAVIT_LNG(8, 2); break;
+    default: return FAVIT_ERR_UNSUPPORTED;
+  }
+#undef FAVIT_LNG
+  (void)nstb;
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
 }

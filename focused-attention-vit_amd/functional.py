@@ -13,6 +13,7 @@ compute-dtype copy that feeds the backward GEMMs.
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -172,6 +173,24 @@ class _LPMirror:
         parameter's current version counter is the one the mirror reflects."""
         self.epoch = _STATE["epoch"]
         self.versions = {id(p): p._version for p in (r() for r in self.params) if p is not None}
+
+    def refresh_if_stale(self) -> bool:
+        """Host-side check for callers that cannot check at use time (a replayed HIP graph reads the mirror without
+        going through lookup): re-cast the whole mirror if any parameter was edited since it was last written."""
+        fp = self.flat_ref()
+        if fp is None:
+            return False
+        stale = self.epoch != _STATE["epoch"]
+        if not stale:
+            for r in self.params:
+                p = r()
+                if p is not None and self.versions.get(id(p), p._version) != p._version:
+                    stale = True
+                    break
+        if stale:
+            K.cast(fp, torch.bfloat16, out=self.lp)
+            self.mark_synced()
+        return stale
 
     def lookup(self, src, w):
         fp = self.flat_ref()
@@ -389,6 +408,30 @@ def lin_fwd(a, w_c, bias, M, N, Kd, out_dtype, *, act=ACT_NONE, residual=None, w
     return (out, pre) if want_pre else out
 
 
+# LayerNorm fused into the qkv / fc1 projections at short token counts (favit_ln_gemm).  OFF by default: built, at
+# parity (tests/test_gpu_kernels.py::test_layernorm_fused_into_small_gemm) and measured at no gain -- cfg3 2.53 ms
+# fused vs 2.48 separate, cfg1 1.90 vs 1.92, cfg5 2.13 vs 2.07: the normalisation is a serial latency chain (load the
+# rows, two reductions, normalise, write the LDS panel) in front of the first MFMA of every workgroup, about as long as
+# the 4.9-us launch it replaces, and it is repeated by the 9-12 column tiles of a row block.  FAVIT_LN_FUSE=1 enables it.
+_LN_FUSE = bool(os.environ.get("FAVIT_LN_FUSE"))
+
+
+def lin_fwd_ln(ln, w_c, bias, M, N, Kd, out_dtype, *, act=ACT_NONE, want_pre=False, drop=(0.0, 0)):
+    """lin_fwd whose A operand is LayerNorm(x): one launch at short token counts (favit_ln_gemm), else layernorm_fwd +
+    lin_fwd.  ln = (x fp32 [M, Kd], gamma, beta).  Returns (out, pre or None, xn, mean, rstd)."""
+    x, gamma, beta = ln
+    if _LN_FUSE and w_c.dtype == torch.bfloat16 and get_compute_mode() != "fp8":
+        out = torch.empty((M, N), dtype=out_dtype, device=x.device)
+        pre = torch.empty((M, N), dtype=out_dtype, device=x.device) if want_pre else None
+        r = K.ln_gemm(x, Kd, gamma, beta, w_c, out, M, N, Kd, bias=bias, act=act, aux_out=pre, dropout_p=drop[0],
+                      dropout_seed=drop[1])
+        if r is not None:
+            return (out, pre) + r
+    xn, mu, rs = K.layernorm_fwd(x, Kd, gamma, beta, M, Kd, get_compute_dtype())
+    o = lin_fwd(xn, w_c, bias, M, N, Kd, out_dtype, act=act, want_pre=want_pre, drop=drop)
+    return (o + (xn, mu, rs)) if want_pre else (o, None, xn, mu, rs)
+
+
 def lin_bwd_x(dy, w_c, M, N, Kd, out_dtype, *, dgelu_pre=None, pre_is_grad=False, drop=(0.0, 0), allow_fp8=True,
               site=None):
     """dx[M,K] = dy[M,N] @ w[N,K]  (optionally * gelu'(pre) * dropout-mask; pre_is_grad: `dgelu_pre` already holds
@@ -406,29 +449,54 @@ def lin_bwd_x(dy, w_c, M, N, Kd, out_dtype, *, dgelu_pre=None, pre_is_grad=False
     return dx
 
 
-# Weight-gradient GEMMs of one block are collected and issued as ONE grouped launch
-# (favit_gemm_grouped_tn): see EncoderOp.bwd / flush_wgrads.
-_WG = {"list": None}
+# Weight-gradient GEMMs are collected -- over SEVERAL blocks at short token counts -- and issued as one grouped launch
+# (favit_gemm_grouped_tn): nothing downstream in the backward chain reads a weight gradient, so the launch can wait,
+# and the more tiles it holds, the fewer K-splits it needs to fill the chip (round 4; csrc/gemm.hip grouped_plan: the
+# twelve blocks of cfg3 in ONE launch without any split, slab or reduction kernel: 19 us per block against 40).
+# How long it waits is bounded by the bytes the waiting operands keep alive (FAVIT_WGRAD_HOLD_MB, default 384: about
+# the Infinity Cache + L2): at 50,432 tokens one block already holds 620 MB, so cfg2 / cfg4 launch per block as
+# before -- measured, four cfg2 blocks per launch make the launch itself 2.5 % faster and the STEP 1 % slower
+# (14.49 vs 14.35 ms; cfg4 28.99 vs 28.82): the held dY buffers are no longer recycled block after block, every
+# input-gradient GEMM writes into memory that is cold in the Infinity Cache and the TLB (those GEMMs: 3.74 -> 3.84 ms).
+# At most four blocks per launch when somebody listens for finished gradients (data parallelism: the buckets of those
+# blocks go out while the rest of backward runs; the graph segments of train.GraphedStep end a launch as well).
+_WG = {"list": None, "blocks": 0, "every": 1, "bytes": 0}
+_WG_HOLD_BYTES = int(float(os.environ.get("FAVIT_WGRAD_HOLD_MB", "384")) * (1 << 20))
 
 
 def begin_wgrads() -> None:
-    _WG["list"] = []
+    every = 4 if _STATE["grad_ready"] is not None else K.GROUP_MAX // 4
+    if _SIDE["enabled"] or os.environ.get("FAVIT_WGRAD_PER_BLOCK"):
+        every = 1                             # (side-stream mode and the A/B switch: one launch per block, as in round 3)
+    _WG.update(list=[], blocks=0, every=every, bytes=0)
 
 
-def flush_wgrads() -> None:
-    """Launch the collected weight-gradient GEMMs (grouped if the library can, else one by one)."""
+def flush_wgrads(force: bool = True) -> bool:
+    """Launch the collected weight-gradient GEMMs (grouped if the library can, else one by one).  force=False: called
+    at the end of a block -- launches only every `every` blocks or once the waiting operands exceed the hold limit.
+    Returns True if the list is empty afterwards."""
     lst = _WG["list"]
-    if not lst:
-        return
-    _WG["list"] = [] if lst is not None else None
-    probs = [(dy, a, dw, db, acc) for dy, a, dw, db, acc, _ in lst]
-    with _side_stream(*[t for pr in probs for t in pr[:4]]):
-        if not K.gemm_grouped_tn(probs):       # (one problem too: fine-tuning with frozen layers leaves only dWeff)
-            for dy, a, dw, db, acc in probs:
-                K.gemm(dy, a, dw, dy.shape[1], a.shape[1], dy.shape[0], dy.stride(0), a.stride(0), dw.stride(0),
-                       a_kmajor=False, b_kmajor=False, a_rowsum=db, accumulate=acc)
-        for *_, ready in lst:
-            _ready(*ready)
+    if lst is None:
+        return True
+    if not force:
+        _WG["blocks"] += 1
+        nb = _WG["blocks"]
+        # (would one more block of the same size still fit the hold limit and the launch?)
+        if nb < _WG["every"] and _WG["bytes"] * (nb + 1) <= _WG_HOLD_BYTES * nb and len(lst) * (nb + 1) <= K.GROUP_MAX * nb:
+            return not lst
+    _WG["blocks"] = 0
+    _WG["bytes"] = 0
+    if lst:
+        _WG["list"] = []
+        probs = [(dy, a, dw, db, acc) for dy, a, dw, db, acc, _ in lst]
+        with _side_stream(*[t for pr in probs for t in pr[:4]]):
+            if not K.gemm_grouped_tn(probs):       # (one problem too: fine-tuning with frozen layers leaves only dWeff)
+                for dy, a, dw, db, acc in probs:
+                    K.gemm(dy, a, dw, dy.shape[1], a.shape[1], dy.shape[0], dy.stride(0), a.stride(0), dw.stride(0),
+                           a_kmajor=False, b_kmajor=False, a_rowsum=db, accumulate=acc)
+            for *_, ready in lst:
+                _ready(*ready)
+    return True
 
 
 def end_wgrads() -> None:
@@ -441,24 +509,20 @@ def end_wgrads() -> None:
 # per layer: 22.9 us x 12 per cfg2 step) and the fold of the LayerNorm dgamma / dbeta partial sums (one per LayerNorm
 # backward: 4.7 us x 24).  Flushed every `every` blocks, so that under data parallelism the buckets that hold these
 # gradients are still reduced while the rest of backward runs, and at the end of the encoder backward.
-_DEFER = {"on": False, "fold": [], "ln": [], "every": 4, "blocks": 0}
+_DEFER = {"on": False, "fold": [], "ln": []}
 
 
 def begin_deferred() -> None:
-    # single process: one batch at the end of the encoder backward; under data parallelism every 4 blocks, so that
-    # the buckets holding these gradients start their all-reduce while the rest of backward still runs
-    _DEFER.update(on=not _SIDE["enabled"], fold=[], ln=[], blocks=0,
-                  every=4 if _STATE["grad_ready"] is not None else 1 << 30)
+    # single process: one batch at the end of the encoder backward; under data parallelism whenever the grouped
+    # weight-gradient launch has gone out (every 4 blocks), so that the buckets holding these gradients start their
+    # all-reduce while the rest of backward still runs.  The fold consumes dWeff: never before that launch.
+    _DEFER.update(on=not _SIDE["enabled"], fold=[], ln=[])
 
 
-def flush_deferred(force: bool = True) -> None:
+def flush_deferred() -> None:
     if not _DEFER["on"]:
         return
-    if not force:
-        _DEFER["blocks"] += 1
-        if _DEFER["blocks"] < _DEFER["every"]:
-            return
-    _DEFER["blocks"] = 0
+    assert not _WG["list"], "the latent_proj fold reads weight gradients that have not been launched"
     fold, ln = _DEFER["fold"], _DEFER["ln"]
     _DEFER["fold"], _DEFER["ln"] = [], []
     if ln:
@@ -522,6 +586,7 @@ def lin_bwd_w(dy, a, M, N, Kd, want_bias=True, wp=None, bp=None, allow_fp8=True)
         # deferred: joins the block's grouped weight-gradient launch
         _WG["list"].append((dy, a, dw, db, tw is not None,
                             [p for p, t in ((wp, tw), (bp, tb)) if t is not None]))
+        _WG["bytes"] += dy.numel() * dy.element_size() + a.numel() * a.element_size()
         return (None if tw is not None else dw), (None if tb is not None else db)
     with _side_stream(dy, a, dw, db):
         # a long-token weight gradient outside a block (patch embedding: 50,176 tokens at cfg2): the grouped launch
@@ -604,16 +669,23 @@ class MHLAChain:
             raise ValueError("window_size must be odd: the reference crashes on even sizes (models/mhla.py:83)")
         self.H, self.W, self.p_attn, self.p_proj = H, W, p_attn, p_proj
 
-    def fwd(self, xn, prm, B, L, residual, mask, training, pre=None):
+    def fwd(self, xn, prm, B, L, residual, mask, training, pre=None, ln=None):
+        """ln = (x, gamma, beta, out): the LayerNorm in front of this branch is fused into the qkv projection (xn is
+        None); out receives (xn, mean, rstd)."""
         wqkv, bqkv, wl, bl, wp, bp = prm
-        M, D = xn.shape
+        M, D = xn.shape if ln is None else ln[0].shape
+        cdt = xn.dtype if ln is None else get_compute_dtype()
         H, hd = self.H, D // self.H
         pa = self.p_attn if training else 0.0
         pp = self.p_proj if training else 0.0
         sa = _seed() if pa > 0 else 0
         sp = _seed() if pp > 0 else 0
-        weff, beff = pre if pre is not None else K.mhla_fold_fwd(wqkv, bqkv, wl, bl, H, xn.dtype)
-        qkv = lin_fwd(xn, weff, beff, M, 3 * D, D, xn.dtype, site=wqkv)
+        weff, beff = pre if pre is not None else K.mhla_fold_fwd(wqkv, bqkv, wl, bl, H, cdt)
+        if ln is not None:
+            qkv, _, xn, mu, rs = lin_fwd_ln(ln[:3], weff, beff, M, 3 * D, D, cdt)
+            ln[3][:] = [xn, mu, rs]
+        else:
+            qkv = lin_fwd(xn, weff, beff, M, 3 * D, D, xn.dtype, site=wqkv)
         # training: the forward also leaves lse per row, and backward runs the saved-statistics kernel (None where
         # that kernel does not apply: other head sizes, fp32)
         o, lse = K.mhla_attn_fwd(qkv, B, L, H, hd, self.W, mask, pa, sa, want_lse=True) if training else \
@@ -638,7 +710,8 @@ class MHLAChain:
         dqkv = K.mhla_attn_bwd(qkv, do, B, L, H, hd, self.W, mask, pa, sa, o=o if lse is not None else None, lse=lse)
         dxn = lin_bwd_x(dqkv, weff, M, 3 * D, D, xn.dtype, site=wqkv)
         dweff, dbeff = lin_bwd_w(dqkv, xn, M, 3 * D, D)
-        flush_wgrads()                      # dW2, dW1, dWproj, dWeff of this block: one grouped launch
+        # (dW2, dW1, dWproj, dWeff join the grouped weight-gradient launch, which may wait for further blocks; the
+        # batched fold below consumes dWeff only after that launch -- EncoderOp.bwd flushes in that order)
         tg = [_gt(p) for p in (wqkv, bqkv, wl, bl)]
         if all(t is not None for t in tg) and _DEFER["on"]:
             _DEFER["fold"].append((dweff, dbeff, wqkv.detach(), bqkv.detach(), wl.detach(), tg, H, (wqkv, bqkv, wl, bl)))
@@ -649,6 +722,7 @@ class MHLAChain:
             _DEFER["fold"].append((dweff, dbeff, wqkv.detach(), bqkv.detach(), wl.detach(), [None, None, tg[2], tg[3]], H,
                                    (wl, bl)))
             return dxn, [None, None, None, None, dwp, dbp]
+        flush_wgrads()                      # the fold runs now: dWeff must have been launched
         if all(t is not None for t in tg):
             with _side_stream(dweff, dbeff):
                 K.mhla_fold_bwd(dweff, dbeff, wqkv, bqkv, wl, H, out=tg)
@@ -673,16 +747,20 @@ class DenseChain:
         ld = 3 * D
         return (_View(t, 0, ld, L * ld, hd), _View(t, D, ld, L * ld, hd), _View(t, 2 * D, ld, L * ld, hd))
 
-    def fwd(self, xn, prm, B, L, residual, mask, training):
+    def fwd(self, xn, prm, B, L, residual, mask, training, ln=None):
         wqkv, bqkv, wp, bp = prm
-        M, D = xn.shape
+        M, D = xn.shape if ln is None else ln[0].shape
         H, hd = self.H, D // self.H
         pa = self.p_attn if training else 0.0
         pp = self.p_proj if (training and not self.torch_mha) else 0.0   # nn.MultiheadAttention has no proj dropout
         sa = _seed() if pa > 0 else 0
         sp = _seed() if pp > 0 else 0
         wqkv_c, wp_c = wcast(wqkv), wcast(wp)
-        qkv = lin_fwd(xn, wqkv_c, bqkv.detach(), M, 3 * D, D, xn.dtype, site=wqkv)
+        if ln is not None:                       # LayerNorm fused into the qkv projection (see MHLAChain.fwd)
+            qkv, _, xn, mu, rs = lin_fwd_ln(ln[:3], wqkv_c, bqkv.detach(), M, 3 * D, D, get_compute_dtype())
+            ln[3][:] = [xn, mu, rs]
+        else:
+            qkv = lin_fwd(xn, wqkv_c, bqkv.detach(), M, 3 * D, D, xn.dtype, site=wqkv)
         o = torch.empty((M, D), dtype=xn.dtype, device=xn.device)
         q, k, v = self._views(qkv, B, L, D, hd)
         ov = _View(o, 0, D, L * D, hd)
@@ -771,9 +849,9 @@ class MLPChain:
         self.p = p
         self.names = (f"{fc1}.weight", f"{fc1}.bias", f"{fc2}.weight", f"{fc2}.bias")
 
-    def fwd(self, xn, prm, residual, training):
+    def fwd(self, xn, prm, residual, training, ln=None):
         w1, b1, w2, b2 = prm
-        M, D = xn.shape
+        M, D = xn.shape if ln is None else ln[0].shape
         Hd = w1.shape[0]
         Do = w2.shape[0]
         p = self.p if training else 0.0
@@ -783,9 +861,15 @@ class MLPChain:
         # Low-precision path: the fc1 epilogue saves GELU'(u) (Phi and phi share one exponential) instead of u, so the
         # backward epilogue is a multiply: the GELU arithmetic (~20 VALU slots per element) runs once instead of twice
         # (measured: -0.09 ms per cfg2 step; both epilogues stay bound by their 310 MB of HBM traffic).  The fp32 parity mode keeps the pre-activation and the exact erf.
-        sg = xn.dtype != torch.float32
-        h, pre = lin_fwd(xn, w1_c, b1.detach(), M, Hd, D, xn.dtype, act=ACT_GELU_SAVEGRAD if sg else ACT_GELU,
-                         want_pre=True, drop=(p, s1), site=w1)
+        if ln is not None:                       # LayerNorm fused into fc1 (bf16 mode only: see EncoderOp.fwd)
+            sg = True
+            h, pre, xn, mu, rs = lin_fwd_ln(ln[:3], w1_c, b1.detach(), M, Hd, D, get_compute_dtype(), act=ACT_GELU_SAVEGRAD,
+                                            want_pre=True, drop=(p, s1))
+            ln[3][:] = [xn, mu, rs]
+        else:
+            sg = xn.dtype != torch.float32
+            h, pre = lin_fwd(xn, w1_c, b1.detach(), M, Hd, D, xn.dtype, act=ACT_GELU_SAVEGRAD if sg else ACT_GELU,
+                             want_pre=True, drop=(p, s1), site=w1)
         y = lin_fwd(h, w2_c, b2.detach(), M, Do, Hd, torch.float32, residual=residual, drop=(p, s2), site=w2)
         return y, (xn, (pre, sg), h, w1_c, w2_c, p, s1, s2, prm)
 
@@ -934,6 +1018,10 @@ class EncoderOp:
         cdt = get_compute_dtype()
         x = _as_f32(x).reshape(M, D)
         tapes = []
+        # short token counts, bf16: the two LayerNorms of a block ride in the A-operand staging of the qkv / fc1
+        # projections (favit_ln_gemm; the library declines shapes beyond the 64-row kernel's regime, and
+        # lin_fwd_ln then issues the two launches)
+        fuse = _LN_FUSE and cdt == torch.bfloat16 and get_compute_mode() == "bf16" and M <= 16384 and D % 64 == 0 and D <= 512
         # the latent_proj folds only depend on parameters: all MHLA blocks of equal geometry in ONE launch
         pre = [None] * len(self.blocks)
         idx, fp, off = [], [], 0
@@ -954,13 +1042,24 @@ class EncoderOp:
             pa = p[2:2 + na]
             g2, b2 = p[2 + na], p[3 + na]
             pm = p[4 + na:]
-            xn1, mu1, rs1 = K.layernorm_fwd(x, D, g1, b1, M, D, cdt)
-            if pre[bi] is not None:
-                x1, sa = bs.attn.fwd(xn1, pa, B, L, x, self.mask, self.training, pre=pre[bi])
+            if fuse and isinstance(bs.attn, (MHLAChain, DenseChain)):
+                o1 = [None, None, None]
+                kw = {"pre": pre[bi]} if pre[bi] is not None else {}
+                x1, sa = bs.attn.fwd(None, pa, B, L, x, self.mask, self.training, ln=(x, g1.detach(), b1.detach(), o1), **kw)
+                xn1, mu1, rs1 = o1
             else:
-                x1, sa = bs.attn.fwd(xn1, pa, B, L, x, self.mask, self.training)
-            xn2, mu2, rs2 = K.layernorm_fwd(x1, D, g2, b2, M, D, cdt)
-            x2, sm = bs.mlp.fwd(xn2, pm, x1, self.training)
+                xn1, mu1, rs1 = K.layernorm_fwd(x, D, g1, b1, M, D, cdt)
+                if pre[bi] is not None:
+                    x1, sa = bs.attn.fwd(xn1, pa, B, L, x, self.mask, self.training, pre=pre[bi])
+                else:
+                    x1, sa = bs.attn.fwd(xn1, pa, B, L, x, self.mask, self.training)
+            if fuse and isinstance(bs.mlp, MLPChain):
+                o2 = [None, None, None]
+                x2, sm = bs.mlp.fwd(None, pm, x1, self.training, ln=(x1, g2.detach(), b2.detach(), o2))
+                xn2, mu2, rs2 = o2
+            else:
+                xn2, mu2, rs2 = K.layernorm_fwd(x1, D, g2, b2, M, D, cdt)
+                x2, sm = bs.mlp.fwd(xn2, pm, x1, self.training)
             tapes.append((x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm))
             x = x2
         return x.reshape(B, L, D), (tapes, B, L, D)
@@ -1009,8 +1108,8 @@ class EncoderOp:
                     pd = nbs.mlp.out_dropout(ntp[9])
                 premasked = pd[0] > 0
                 g, g_lp, dg1, db1 = ln_bwd(dxn1, x, g1, b1, mu1, rs1, g, pd)
-                flush_wgrads()
-                flush_deferred(force=False)
+                if flush_wgrads(force=False) and _STATE["grad_ready"] is not None:
+                    flush_deferred()
                 if not _SIDE["enabled"]:
                     join_side_stream()
                 grads = [dg1, db1] + ga + [dg2, db2] + gm + grads

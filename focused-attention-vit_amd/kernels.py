@@ -119,6 +119,44 @@ def gemm(A, B, Cc, M, N, K, lda, ldb, ldc, *, a_kmajor=True, b_kmajor=True, bias
     GEMM_TRACE.append((e0, e1, 2.0 * M * N * K * batch, key, (M, N, K, batch), _abi.lib().favit_gemm_last_kernel().decode()))
 
 
+def ln_gemm(x, ldx, gamma, beta, w, out, M, N, D, *, bias=None, act=ACT_NONE, aux_out=None, residual=None,
+            dropout_p=0.0, dropout_seed=0, eps=1e-5):
+    """out = epilogue(LayerNorm(x) @ w^T) in one launch (favit_ln_gemm); returns (xn bf16 [M, D], mean, rstd), or None
+    when the library declines the shape (the caller then runs layernorm_fwd + gemm)."""
+    require_gpu(x, gamma, beta, w, out)
+    if w.dtype != torch.bfloat16 or x.dtype != torch.float32:
+        return None
+    d = GemmDesc()
+    d.A = None
+    d.B, d.C = w.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.aux_out = aux_out.data_ptr() if aux_out is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.M, d.N, d.K = M, N, D
+    d.lda, d.ldb, d.ldc = D, w.stride(0), out.stride(0)
+    d.ld_aux_out, d.ld_res = N, N
+    d.batch, d.batch_inner = 1, 1
+    d.a_kmajor, d.b_kmajor = 1, 1
+    d.in_dtype, d.out_dtype = BF16, dt(out)
+    d.act, d.alpha = act, 1.0
+    d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
+    xn = torch.empty((M, D), dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    if GEMM_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _abi.lib().favit_ln_gemm(C.byref(d), _p(x), ldx, _p(gamma), _p(beta), eps, _p(xn), _p(mean), _p(rstd), _st())
+    if rc == -2:
+        return None
+    _abi.check(rc, "favit_ln_gemm")
+    if GEMM_TRACE is not None:
+        e1.record()
+        GEMM_TRACE.append((e0, e1, 2.0 * M * N * D, "bf16_KK_" + ("obf16" if out.dtype == torch.bfloat16 else "of32"),
+                           (M, N, D, 1), "s64ln"))
+    return xn, mean, rstd
+
+
 _GROUPED_WS = {}          # device index -> workspace tensor of the slab-mode split-K reduction
 # Workspaces that were outgrown stay alive: a captured HIP graph holds their ADDRESS (train.GraphedStep: one graph per
 # token-count bucket, the second bucket can need a larger workspace than the first), and torch.cuda.graph() empties the
@@ -127,12 +165,25 @@ _GROUPED_WS = {}          # device index -> workspace tensor of the slab-mode sp
 _GROUPED_WS_RETIRED = []
 
 
+GROUP_MAX = 48            # problems per grouped launch (csrc/gemm.hip)
+
+
 def gemm_grouped_tn(problems, use_workspace: bool = True) -> bool:
-    """One launch for several weight-gradient GEMMs dW = dY^T X that share the token dim.
+    """One launch for several weight-gradient GEMMs dW = dY^T X that share the token dim (more than GROUP_MAX problems:
+    consecutive launches of GROUP_MAX).
     problems: list of (dy [T,N], a [T,K], dw [N,K] fp32, db [N] fp32 or None, accumulate: bool).
     Returns False if the library cannot group them (caller falls back to single launches).
-    use_workspace: partial results of the K-splits go through a cached device workspace and are summed in a fixed
-    order (deterministic, no fp32 atomics); False keeps the atomic path."""
+    use_workspace: when the library splits the token dimension, the partial results of the K-splits go through a
+    cached device workspace and are summed in a fixed order (deterministic, no fp32 atomics); False keeps the atomic
+    path.  With enough tiles in the launch there is ONE split and the tiles write dW themselves (no workspace)."""
+    if len(problems) > GROUP_MAX:
+        T = problems[0][0].shape[0]
+        if any(p[0].shape[0] != T or p[0].dtype != torch.bfloat16 or p[1].dtype != torch.bfloat16 for p in problems) or T % 32:
+            return False                               # decline as a whole: never half a list
+        for i in range(0, len(problems), GROUP_MAX):
+            if not gemm_grouped_tn(problems[i:i + GROUP_MAX], use_workspace):
+                raise RuntimeError("grouped weight-gradient launch declined a chunk after launching another")
+        return True
     n = len(problems)
     if n == 0:
         return True
@@ -155,14 +206,14 @@ def gemm_grouped_tn(problems, use_workspace: bool = True) -> bool:
     if GEMM_TRACE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    if use_workspace:
-        need = int(_abi.lib().favit_gemm_grouped_tn_workspace(arr, n))
+    need = int(_abi.lib().favit_gemm_grouped_tn_workspace(arr, n)) if use_workspace else 0
+    if need > 0:
         dev = problems[0][0].device
         ws = _GROUPED_WS.get(dev.index)
         if ws is None or ws.numel() < need:
             if ws is not None:
                 _GROUPED_WS_RETIRED.append(ws)
-            ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
             _GROUPED_WS[dev.index] = ws
         rc = _abi.lib().favit_gemm_grouped_tn_ws(arr, n, _p(ws), ws.numel(), _st())
     else:
@@ -173,7 +224,8 @@ def gemm_grouped_tn(problems, use_workspace: bool = True) -> bool:
     if GEMM_TRACE is not None:
         e1.record()
         fl = sum(2.0 * p[0].shape[0] * p[0].shape[1] * p[1].shape[1] for p in problems)
-        GEMM_TRACE.append((e0, e1, fl, "bf16_MM_of32_grouped", (len(problems),), "grouped_tn"))
+        GEMM_TRACE.append((e0, e1, fl, "bf16_MM_of32_grouped", (len(problems), int(_abi.lib().favit_gemm_grouped_last_splits())),
+                           "grouped_tn"))
     return True
 
 

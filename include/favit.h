@@ -127,11 +127,23 @@ int favit_gemm(const favit_gemm_t* g, void* stream);
  * 128x128 / exact-fp32) the calling host thread's last favit_gemm dispatched to.  Static string, never NULL. */
 const char* favit_gemm_last_kernel(void);
 
-/* Grouped weight-gradient GEMMs: `count` (<= 8) problems dW_i = dY_i^T . X_i that share the token
- * dimension K (e.g. the four nn.Linear layers of one transformer block) as ONE launch.  Every
- * problem must be bf16 in / fp32 out with a_kmajor = b_kmajor = 0, no epilogue other than
- * a_rowsum (bias gradient) and accumulate; returns FAVIT_ERR_UNSUPPORTED otherwise (the caller
- * then issues them one by one). */
+/* LayerNorm fused into a small-M forward GEMM (v7):  C = epilogue( LN(x; gamma, beta, eps) . B^T )  in ONE launch, for
+ * the short-token configurations where a block's forward is a chain of 5-15 us launches.  `g` describes the GEMM as for
+ * favit_gemm with A ignored: bf16 k-major weights B [N, K], K = the LayerNorm width (a multiple of 64, <= 512, not 320 /
+ * 448), every epilogue of favit_gemm (bias, GELU variants, dropout, residual), no split-K / batch / accumulate.
+ * x: fp32 rows of ldx.  Also written: xn [M, K] bf16 (the normalised rows, the A operand of the weight-gradient GEMM),
+ * mean [M], rstd [M] (fp32) for favit_layernorm_bwd.  Same arithmetic as favit_layernorm_fwd followed by favit_gemm
+ * (two-pass variance, bf16 rounding of xn before the product); FAVIT_ERR_UNSUPPORTED for other shapes / dtypes (the
+ * caller then issues the two launches). */
+int favit_ln_gemm(const favit_gemm_t* g, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                  void* xn, float* mean, float* rstd, void* stream);
+
+/* Grouped weight-gradient GEMMs: `count` (<= 48) problems dW_i = dY_i^T . X_i that share the token
+ * dimension K (the four nn.Linear layers of one transformer block, or of several consecutive blocks) as
+ * ONE launch.  Every problem must be bf16 in / fp32 out with a_kmajor = b_kmajor = 0, no epilogue other
+ * than a_rowsum (bias gradient, always ADDED to its destination) and accumulate; returns
+ * FAVIT_ERR_UNSUPPORTED otherwise (the caller then issues them one by one).  The number of K-splits is
+ * chosen by a cost model (v7): with enough tiles in the launch it is 1, and then no workspace is used. */
 int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void* stream);
 /* The same launch with a caller-provided device workspace of favit_gemm_grouped_tn_workspace(gs, count) bytes:
  * every K-split writes its partial results to a slab of the workspace with plain stores and a second kernel adds
@@ -140,6 +152,8 @@ int favit_gemm_grouped_tn(const favit_gemm_t* gs, int32_t count, void* stream);
 int64_t favit_gemm_grouped_tn_workspace(const favit_gemm_t* gs, int32_t count);
 int favit_gemm_grouped_tn_ws(const favit_gemm_t* gs, int32_t count, void* workspace, int64_t workspace_bytes,
                              void* stream);
+/* Diagnostic: K-splits of the calling host thread's last grouped launch (1 = tiles wrote dW directly). */
+int favit_gemm_grouped_last_splits(void);
 
 /* ------------------------------------------------------------------------------------
  * FP8 operand preparation (BASELINE.json configs[3] "fp8 MFMA path"; no reference counterpart:

@@ -507,6 +507,58 @@ def test_cross_entropy_and_adamw(K):
     assert torch.equal(lp, p.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("M,D,N,mode", [(128 * 17, 384, 1152, "plain"), (128 * 17, 384, 1536, "gelu"), (64 * 65, 192, 576, "plain"),
+                                       (64 * 65, 192, 768, "gelu"), (1000 - 3, 256, 200, "plain"), (333, 64, 1000, "gelu"),
+                                       (700, 512, 384, "plain"), (2176, 128, 128, "gelu")])
+def test_layernorm_fused_into_small_gemm(K, favit, M, D, N, mode):
+    """favit_ln_gemm (LayerNorm in the A-operand staging of the 64-row GEMM) == favit_layernorm_fwd followed by
+    favit_gemm: the saved xn / mean / rstd and the product, against the two-launch path and an fp32 restatement."""
+    g = torch.Generator(device=DEV).manual_seed(M + D + N)
+    x = torch.randn(M, D, device=DEV, generator=g) * 1.7 + 0.3
+    gamma = torch.randn(D, device=DEV, generator=g) * 0.2 + 1.0
+    beta = torch.randn(D, device=DEV, generator=g) * 0.1
+    w = (torch.randn(N, D, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g) * 0.1
+    act = favit._abi.ACT_GELU_SAVEGRAD if mode == "gelu" else favit._abi.ACT_NONE
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    pre = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV) if mode == "gelu" else None
+    r = K.ln_gemm(x, D, gamma, beta, w, out, M, N, D, bias=bias, act=act, aux_out=pre)
+    assert r is not None, "the library must take this shape"
+    xn, mean, rstd = r
+    xn2, mean2, rstd2 = K.layernorm_fwd(x, D, gamma, beta, M, D, torch.bfloat16)
+    out2 = torch.empty_like(out)
+    pre2 = torch.empty_like(out) if mode == "gelu" else None
+    K.gemm(xn2, w, out2, M, N, D, D, D, N, bias=bias, act=act, aux_out=pre2, ld_aux_out=N)
+    torch.cuda.synchronize()
+    assert rel_l2(mean, mean2) < 1e-6 and rel_l2(rstd, rstd2) < 1e-6
+    # the same arithmetic up to the summation order of the two reductions: bf16 values differ by at most one rounding
+    assert float((xn.float() - xn2.float()).abs().max()) <= 2.0 ** -7 * float(xn2.float().abs().max())
+    assert rel_l2(xn, xn2) < 1e-3
+    assert rel_l2(out, out2) < 4e-3
+    ref_xn = torch.nn.functional.layer_norm(x, (D,), gamma, beta)
+    ref = ref_xn.to(torch.bfloat16).float() @ w.float().t() + bias
+    if mode == "gelu":
+        assert rel_l2(pre, pre2) < 4e-3
+        u = ref.double()
+        dref = 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+        assert rel_l2(pre, dref) < 1e-2
+        ref = torch.nn.functional.gelu(ref)
+    assert rel_l2(out, ref) < 1e-2
+    assert torch.isfinite(out.float()).all()
+
+
+def test_layernorm_fused_gemm_declines_large_or_odd_shapes(K):
+    x = torch.randn(50432, 384, device=DEV)
+    gm, bt = torch.ones(384, device=DEV), torch.zeros(384, device=DEV)
+    w = torch.randn(1152, 384, device=DEV).to(torch.bfloat16)
+    out = torch.empty(50432, 1152, dtype=torch.bfloat16, device=DEV)
+    assert K.ln_gemm(x, 384, gm, bt, w, out, 50432, 1152, 384) is None            # cfg2: the large-tile kernels' regime
+    x = torch.randn(256, 320, device=DEV)
+    w = torch.randn(128, 320, device=DEV).to(torch.bfloat16)
+    out = torch.empty(256, 128, dtype=torch.bfloat16, device=DEV)
+    assert K.ln_gemm(x, 320, torch.ones(320, device=DEV), torch.zeros(320, device=DEV), w, out, 256, 128, 320) is None
+
+
 def test_zero_fills_survive_graph_replays(K):
     """The launches that zero a destination and then add into it with atomics (embed-prologue backward: cls_token /
     pos_embed gradients; latent_proj fold backward), captured ONCE in a HIP graph and replayed: every replay equals the
