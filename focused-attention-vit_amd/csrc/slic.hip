@@ -153,7 +153,10 @@ __device__ __forceinline__ int masked_wave_sum(int v, bool in) {
 // form this replaces (and to oracle/slic_oracle.py).  The old kernel stopped at the first iteration that changed no
 // label; further iterations of a fixed point reproduce it, so running all of them gives the same labels.
 __host__ __device__ __forceinline__ size_t slic_ws_stride(int K) {       // bytes per image, a multiple of 8
-  return (size_t)K * 48 + (((size_t)K * 20 + 7) & ~(size_t)7);
+  return (size_t)K * 48 + (((size_t)K * 20 + 7) & ~(size_t)7) + 8;      // + the arrival counter of the assignment pass
+}
+__device__ __forceinline__ unsigned* slic_arrivals(void* ws, int b, int K) {
+  return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + (size_t)(b + 1) * slic_ws_stride(K) - 8);
 }
 __device__ __forceinline__ long long* slic_sums(void* ws, int b, int K) {
   return reinterpret_cast<long long*>(reinterpret_cast<char*>(ws) + (size_t)b * slic_ws_stride(K));
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(64) void slic_seed_kernel(const short* __restrict__
   long long* sm = slic_sums(ws, b, K) + tid * 6;
 #pragma unroll
   for (int c = 0; c < 6; ++c) sm[c] = 0;
+  if (tid == 0) *slic_arrivals(ws, b, K) = 0u;
 }
 
 // FAST (H, W <= 2047 and coef < 2^32, i.e. every real call): every difference fits 16 bits and every sum of squares 31
@@ -322,20 +326,30 @@ __global__ __launch_bounds__(ASG_THREADS) void slic_assign_kernel(const short* _
   for (int i = tid; i < K * 6; i += ASG_THREADS)
     if (sums[i / 6][i % 6] != 0)
       atomicAdd(reinterpret_cast<unsigned long long*>(slic_sums(ws, b, K)) + i, (unsigned long long)(long long)sums[i / 6][i % 6]);
-}
-
-__global__ __launch_bounds__(64) void slic_update_kernel(void* ws, int K) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid >= K) return;
-  long long* sm = slic_sums(ws, b, K) + tid * 6;
-  int* cen = slic_cen(ws, b, K) + tid * 5;
-  const long long n = sm[5];
-  if (n > 0) {
+  // The centre update rides on the LAST workgroup of the image to arrive (round 4: one launch per iteration instead
+  // of two -- ten 4.5-us launches per call): every workgroup publishes its sums (agent-scope fence), then takes a
+  // ticket; the one that draws the last ticket sees every other workgroup's atomics, divides, clears the sums and the
+  // ticket counter for the next iteration.  Exact integers as before: the order of arrival changes nothing.
+  __shared__ unsigned last_flag;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) last_flag = atomicAdd(slic_arrivals(ws, b, K), 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!last_flag) return;
+  __threadfence();
+  if (tid < K) {
+    // (atomic reads: the sums were written by other workgroups' L2 atomics; never through this CU's vector cache)
+    unsigned long long* sm = reinterpret_cast<unsigned long long*>(slic_sums(ws, b, K)) + tid * 6;
+    int* cn = slic_cen(ws, b, K) + tid * 5;
+    long long v[6];
 #pragma unroll
-    for (int c = 0; c < 5; ++c) cen[c] = (int)(sm[c] / n);                  // truncation toward zero
+    for (int c = 0; c < 6; ++c) v[c] = (long long)atomicExch(sm + c, 0ull);
+    if (v[5] > 0) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) cn[c] = (int)(v[c] / v[5]);                // truncation toward zero
+    }
   }
-#pragma unroll
-  for (int c = 0; c < 6; ++c) sm[c] = 0;
+  if (tid == 0) *slic_arrivals(ws, b, K) = 0u;
 }
 
 // ---- stage 3: connected components by union-find (link the larger root under the smaller: the root of a component is
@@ -593,8 +607,6 @@ extern "C" int favit_slic_cluster(const int16_t* feat, uint8_t* labels, const in
     else
       hipLaunchKernelGGL(slic_assign_kernel<false>, grid, dim3(ASG_THREADS), (size_t)16 * (K * 6 + 1) * 4, st, reinterpret_cast<const short*>(feat), labels,
                          ws, K, H, W, step, (long long)coef FAVIT_SLIC_DBG_ARG);
-    FAVIT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(slic_update_kernel, dim3((unsigned)B), dim3(64), 0, st, ws, K);
     FAVIT_CHECK_LAUNCH();
   }
   return FAVIT_OK;

@@ -157,10 +157,17 @@ class DeviceLoader:
     (uint8 [B,H,W,C] array / tensor, integer labels).  Batch k+1 is copied (pinned staging buffers, a dedicated
     copy stream) and transformed while the consumer computes on batch k: no host-side blocking .to(device)."""
 
-    def __init__(self, host_batches: Iterable, transform: DeviceTransform, device: Optional[torch.device] = None):
+    def __init__(self, host_batches: Iterable, transform: DeviceTransform, device: Optional[torch.device] = None,
+                 segmenter=None):
+        """segmenter (optional): a models.sppp.SuperpixelSegmentation (``model.segmentation`` of the SPPP models).  The
+        label maps of batch k+1 are then computed by the device SLIC on the loader's preparation stream while the
+        consumer trains on batch k, and installed (``set_label_maps``) when the batch is yielded -- the reference
+        segments inside forward (models/sppp_mhla.py:278), on the critical path of every step."""
         self.src, self.tf = host_batches, transform
         self.dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.segmenter = segmenter
+        self.prep_stream = torch.cuda.Stream(device=self.dev) if segmenter is not None else None
         self._pin = [None, None]
 
     def __len__(self):
@@ -192,6 +199,16 @@ class DeviceLoader:
             ev.record(self.copy_stream)
         if src[0] is not imgs:
             self._pin[slot][2] = ev
+        if self.segmenter is not None:
+            # transform + SLIC of this (next) batch now, on a stream of their own, under the consumer's current step
+            with torch.cuda.stream(self.prep_stream):
+                self.prep_stream.wait_event(ev)
+                x = self.tf(d_img)
+                maps = self.segmenter.segment_device(x)
+                d_img.record_stream(self.prep_stream)
+                ev2 = torch.cuda.Event()
+                ev2.record(self.prep_stream)
+            return (x, maps), d_lab, ev2
         return d_img, d_lab, ev
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
@@ -213,6 +230,12 @@ class DeviceLoader:
         d_img, d_lab, ev = staged
         cs = torch.cuda.current_stream(self.dev)
         cs.wait_event(ev)                                 # device-side wait, the host does not block
-        d_img.record_stream(cs)
         d_lab.record_stream(cs)
+        if self.segmenter is not None:
+            x, maps = d_img
+            x.record_stream(cs)
+            maps.record_stream(cs)
+            self.segmenter.set_label_maps(maps)           # the model's next segment() call returns them
+            return x, d_lab
+        d_img.record_stream(cs)
         return self.tf(d_img), d_lab

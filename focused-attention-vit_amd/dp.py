@@ -130,8 +130,22 @@ class GradSync:
     """Bucketed, overlapped all-reduce (mean) of a FlatBuffers' gradient buffer."""
 
     def __init__(self, flat: FlatBuffers, bucket_mb: Optional[float] = None,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, wire_dtype: Optional[torch.dtype] = None):
+        """wire_dtype=torch.bfloat16 (or FAVIT_DP_WIRE=bf16): the buckets travel as bf16 -- half the bytes per xGMI
+        link, which is what bounds a ring all-reduce on this node (at 17 tokens per image the 88 MB
+        fp32 exchange is as long as the step it follows).  The kernels keep accumulating into the fp32 flat buffer; at
+        launch a bucket is rounded into a persistent bf16 wire buffer (stream-ordered behind its last writer), the
+        collective sums bf16, and finish() widens the reduced values back into the fp32 buffer the fused AdamW reads
+        (moments and master weights stay fp32).  Deviation from the fp32 exchange: one bf16 rounding of every rank's
+        contribution plus the collective's bf16 partial sums, <= ~world x 2^-9 relative per element
+        (tests/test_dp_gloo.py bounds it at world_size 2).  Opt-in: the default exchange is fp32."""
         self.flat, self.group = flat, group
+        if wire_dtype is None and os.environ.get("FAVIT_DP_WIRE", "").lower() in ("bf16", "bfloat16"):
+            wire_dtype = torch.bfloat16
+        if wire_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("GradSync wire_dtype must be None / torch.float32 / torch.bfloat16")
+        self.wire_dtype = None if wire_dtype == torch.float32 else wire_dtype
+        self._wire = torch.zeros(flat.numel, dtype=self.wire_dtype, device=flat.flat_g.device) if self.wire_dtype is not None else None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # FAVIT_DP_FORCE=1: issue the collectives in a one-rank group too (tests/test_dp_gpu.py: the real RCCL call
         # path -- async all-reduce of flat-buffer slices from the autograd thread -- on a one-GPU box)
@@ -230,6 +244,7 @@ class GradSync:
         self._seen = [dict() for _ in self.buckets]      # parameter index -> reported directly by the kernels?
         self._handles = []
         self._snap = []
+        self._widen = []                                  # (fp32 slice, bf16 wire slice) of every bucket launched in bf16
 
     def _launch(self, b):
         if self._launched[b] or not self._active:
@@ -241,6 +256,13 @@ class GradSync:
             _dbg(f"launch sync#{id(self) % 9973} bucket {b} [{s}:{e}) thread {threading.current_thread().name}")
         if _VERIFY:
             self._snap.append((b, buf.clone()))
+        if self._wire is not None:
+            # bf16 on the wire: round the bucket into the wire buffer on the compute stream (behind its last writer by
+            # stream order); the collective and everything below work on that slice, finish() widens it back
+            wire = self._wire[s:e]
+            wire.copy_(buf)
+            self._widen.append((buf, wire))
+            buf = wire
         if self._host_staged and buf.is_cuda and not _NO_DRAIN:
             # gloo stages device tensors through pinned host memory: the op makes one of gloo's pool streams WAIT (on
             # the device) for an event recorded on the calling thread's current stream -- here the compute stream, with
@@ -293,7 +315,8 @@ class GradSync:
             err = (got - ref).abs().max().item()
             scale = ref.abs().max().item()
             worst = max(worst, err / max(scale, 1e-30))
-            if err > 1e-5 * max(scale, 1e-30):
+            tol = 1e-5 if self._wire is None else 2.0 ** -7 * max(2, self.world)      # bf16 wire: rounding, not ordering
+            if err > tol * max(scale, 1e-30):
                 raise RuntimeError(f"FAVIT_DP_VERIFY: bucket {b} [{s}:{e}) differs from the synchronous reduction of its "
                                    f"launch-time snapshot by {err:.3e} (max |ref| {scale:.3e}): a writer of this slice was "
                                    "not ordered before the collective")
@@ -315,6 +338,8 @@ class GradSync:
                 h.wait()
             if _DEBUG:
                 _dbg(f"done sync#{id(self) % 9973}")
+            for dst, wire in self._widen:                 # the reduced bf16 values back into the fp32 gradient buffer
+                dst.copy_(wire)
             if _VERIFY:
                 self._verify()
             if average:

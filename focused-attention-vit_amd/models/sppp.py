@@ -34,6 +34,12 @@ class SuperpixelSegmentation:
         """Install precomputed label maps [B,H,W] (int64) returned by the next segment() calls."""
         self._maps = maps
 
+    def segment_device(self, images: torch.Tensor) -> torch.Tensor:
+        """Device SLIC of a batch [B,3,H,W] on the current stream, ignoring installed maps (data.DeviceLoader calls it
+        for the NEXT batch on its preparation stream and installs the result when that batch is yielded)."""
+        return K.slic(images.float(), n_segments=self.num_segments, compactness=self.compactness, sigma=self.sigma,
+                      rescale=self.rescale_input)
+
     def segment(self, image: torch.Tensor) -> torch.Tensor:
         """Label maps [B,H,W] (or [H,W]) int64.  Installed maps win; images on the GPU run the device SLIC
         (csrc/slic.hip: no D2H -> skimage -> H2D hop per image; parity with scikit-image is unpinned, the

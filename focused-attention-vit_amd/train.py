@@ -63,7 +63,7 @@ class FusedAdamW:
     gradient buffers, see dp.py)."""
 
     def __init__(self, groups, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05, bucket_mb=None,
-                 distributed=None):
+                 distributed=None, wire_dtype=None):
         if isinstance(groups, torch.nn.Module):
             groups = [{"params": list(groups.parameters())}]
         elif groups and not isinstance(groups[0], dict):
@@ -77,7 +77,7 @@ class FusedAdamW:
                 "weight_decay": g.get("weight_decay", weight_decay),
                 "m": torch.zeros_like(flat.flat_p), "v": torch.zeros_like(flat.flat_p),
                 "lp": torch.empty(flat.numel, dtype=torch.bfloat16, device=flat.flat_p.device) if flat.flat_p.is_cuda else None,
-                "sync": GradSync(flat, bucket_mb) if dist_on else None,
+                "sync": GradSync(flat, bucket_mb, wire_dtype=wire_dtype) if dist_on else None,
             })
             self.groups[-1]["mirror"] = None
             if self.groups[-1]["lp"] is not None:

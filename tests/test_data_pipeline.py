@@ -93,6 +93,34 @@ def test_device_loader_matches_direct_transform_and_overlaps(favit):
 
 
 @pytest.mark.gpu
+def test_device_loader_prefetches_label_maps_for_the_sppp_models(favit):
+    """DeviceLoader(segmenter=model.segmentation): the device SLIC of batch k+1 runs on the loader's preparation stream
+    under the consumer's work on batch k; when a batch is yielded its label maps are installed, i.e. the model's
+    segment() call (reference: inside forward, models/sppp_mhla.py:278) returns exactly what segmenting the yielded
+    images directly gives."""
+    D = favit.data
+    rs = np.random.RandomState(3)
+    low = rs.randint(0, 256, size=(4, 8, 7, 7, 3), dtype=np.uint8)                  # blocky images: clear regions
+    batches = [(np.kron(low[i], np.ones((1, 8, 8, 1), dtype=np.uint8)), rs.randint(0, 10, size=8)) for i in range(4)]
+    tf = D.DeviceTransform("resize", 64, D.CIFAR10_MEAN, D.CIFAR10_STD)
+    seg = favit.models.sppp.SuperpixelSegmentation(num_segments=16, compactness=10.0)
+    loader = D.DeviceLoader(batches, tf, segmenter=seg)
+    n = 0
+    for (x, y), (hi, hl) in zip(loader, batches):
+        ref_x = tf(torch.from_numpy(hi).to(DEV))
+        assert torch.equal(x, ref_x) and torch.equal(y.cpu(), torch.from_numpy(hl))
+        got = seg.segment(x)                                         # what the model's forward would receive
+        # (busy work on the consumer stream while the loader's next batch is being segmented on its own stream)
+        _ = (x @ x.transpose(-1, -2)).sum()
+        want = seg.segment_device(x)
+        assert got.dtype == torch.int64 and tuple(got.shape) == (8, 64, 64)
+        assert torch.equal(got, want)
+        n += 1
+    assert n == 4
+    seg.set_label_maps(None)
+
+
+@pytest.mark.gpu
 def test_harness_epoch_loop_and_measurements(favit, tmp_path):
     """fit / evaluate / measure_* on a tiny model and a synthetic uint8 dataset: the loss goes down, the result row
     has the reference's columns (experiments/mhla_pretrained.py:486-525), timers return positive device times."""

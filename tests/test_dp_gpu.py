@@ -82,7 +82,7 @@ def test_dp_two_ranks_through_the_kernels(favit, tmp_path, mode, tol):
         favit.set_compute_dtype("fp32")
 
 
-def _nccl_worker(rank, port, out):
+def _nccl_worker(rank, port, out, wire=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -94,7 +94,8 @@ def _nccl_worker(rank, port, out):
     pkg = importlib.import_module("focused-attention-vit_amd")
     pkg.set_compute_dtype("bf16")
     m = _model(pkg)
-    opt = pkg.train.FusedAdamW(pkg.train.param_groups(m, lr=1e-2), lr=1e-2, weight_decay=0.0, bucket_mb=0.05)
+    opt = pkg.train.FusedAdamW(pkg.train.param_groups(m, lr=1e-2), lr=1e-2, weight_decay=0.0, bucket_mb=0.05,
+                               wire_dtype=wire)
     n_buckets = sum(len(g["sync"].buckets) for g in opt.groups)
     x, y = _batch()
     xs, ys = x.cuda(), y.cuda()
@@ -137,6 +138,22 @@ def test_rccl_call_path_single_rank(favit, tmp_path):
             assert err < 2e-2, (k, float(err))
     finally:
         favit.set_compute_dtype("fp32")
+
+
+def test_rccl_bf16_wire_mode_single_rank(favit, tmp_path):
+    """The opt-in bf16 exchange (dp.GradSync wire_dtype) on RCCL: bf16 all-reduce of the wire buffer's slices on the
+    one-rank group, widened back into the fp32 gradient buffer.  A one-rank sum is the identity: the gradients the
+    optimizer sees are the single-process ones rounded to bf16 once (and training still converges)."""
+    out = str(tmp_path / "nccl_bf16.pt")
+    mp.spawn(_nccl_worker, args=(36500 + (os.getpid() % 2000), out, torch.bfloat16), nprocs=1, join=True)
+    r = torch.load(out, weights_only=True)
+    assert all(r["launched"]) and r["n_handles"] == r["n_buckets"] >= 3
+    assert r["losses"][-1] < r["losses"][0]
+    rounded = 0
+    for k, g in r["grads"].items():
+        assert torch.isfinite(g).all(), k
+        rounded += int(torch.equal(g.to(torch.bfloat16).float(), g))
+    assert rounded == len(r["grads"]), "every gradient went through the bf16 wire buffer"
 
 
 def _graph_worker(rank, world, port, out):
