@@ -1573,6 +1573,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_s64_kernel(KParams p) {
   for (int j = 0; j < 2; ++j) sa[j] = glds_src<true>(A, p.lda, m0, p.M, 0, wave * 2 + j, lane);
 #pragma unroll
   for (int j = 0; j < 4; ++j) sb[j] = glds_src<BKM>(Bm, p.ldb, n0, p.N, 0, wave * 4 + j, lane);
+#ifdef FAVIT_PROBE
+  // dbg 0x4000 (timing only, wrong results): only HALF of the B pieces are streamed -- what a k-step of a 64x64 tile
+  // (16 KB instead of 24 KB per stage) would cost in this kernel's structure
+  const bool half_b = (p.dbg & 0x4000) != 0;
+#else
+  constexpr bool half_b = false;
+#endif
   auto issue = [&](int buf) {
     char* st = smem + buf * S64_STAGE;
 #pragma unroll
@@ -1582,6 +1589,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_s64_kernel(KParams p) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      if (half_b && j >= 2) continue;
       __builtin_amdgcn_global_load_lds((gptr_t)sb[j], (lptr_t)(st + S64_A_BYTES + (wave * 4 + j) * 1024), 16, 0, 0);
       sb[j] += BKM ? BK16 : BK16 * p.ldb;
     }
@@ -1590,7 +1598,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_s64_kernel(KParams p) {
   if (nk > 1) issue(1);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (kt + 1 < nk) { if (half_b) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);
@@ -1613,6 +1621,121 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_s64_kernel(KParams p) {
   __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
   wave_epilogue_rows<bf16_t, OutT, 0, 2>(p, acc, C, m0 + wr * 32, n0 + wc * 64, lane,
                                          reinterpret_cast<float*>(smem + wave * WEPI_BYTES), true, p.alpha);
+}
+
+// --------------------------------------------------------------------------------------
+// bf16 kernel "s64k2": the 64x128 tile of s64 with the K loop split between TWO groups of four waves (waves w and
+// w + 4 share a SIMD): group g takes k-steps g, g + 2, ... through a ring of its own, so two k-steps of the tile are
+// in flight on the CU at any time, and the halves are added through LDS before the (shared) epilogue.  For launches
+// with no more tiles than CUs (the N = 384 projections at 17 tokens per image: 102 tiles): such a launch is ONE
+// latency-bound workgroup per CU whose time is 6.6 us + 0.33 us per k-step -- and that per-k-step cost is the
+// dependency chain barrier -> fragment reads -> MFMAs of a lone wave per SIMD, not bytes: streaming only half of the B
+// operand (probe build, FAVIT_GEMM_DBG=0x4000) leaves every launch unchanged (fc2 at 2,176 tokens: 15.8 us both ways).
+// Deterministic: wave (g, w) ends up with rows 16 g .. 16 g + 15 of wave tile w as own + partner, one fp32 addition.
+// --------------------------------------------------------------------------------------
+constexpr int S64K2_THREADS = 512;
+constexpr int S64K2_LDS = 2 * S64_LDS;                   // 147456
+
+template <bool BKM, typename OutT>
+__global__ __launch_bounds__(S64K2_THREADS) void gemm_bf16_s64k2_kernel(KParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave8 >> 2, wave = wave8 & 3;          // k-step parity of this wave, wave inside its group
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const long m0 = (long)(tile / p.tiles_n) * S64_BM;
+  const long n0 = (long)(tile % p.tiles_n) * BN;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* Bm = reinterpret_cast<const bf16_t*>(p.B);
+  OutT* C = reinterpret_cast<OutT*>(p.C);
+  const int nk = (int)(p.K / BK16);
+  const int nit = (nk + 1) >> 1;                         // iterations of BOTH groups (one barrier each)
+  const int mine = (nk - grp + 1) >> 1;                  // k-steps this group really has
+  char* ring = smem + grp * S64_LDS;
+
+  f32x4 acc[4][4];                        // rows 0..31 of the wave tile live in acc[0..1][*]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bf16_t* sa[2];
+  const bf16_t* sb[4];
+  const long k0 = (long)grp * BK16;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) sa[j] = glds_src<true>(A, p.lda, m0, p.M, k0, wave * 2 + j, lane);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sb[j] = glds_src<BKM>(Bm, p.ldb, n0, p.N, k0, wave * 4 + j, lane);
+  auto issue = [&](int buf) {
+    char* st = ring + buf * S64_STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + (wave * 2 + j) * 1024), 16, 0, 0);
+      sa[j] += 2 * BK16;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sb[j], (lptr_t)(st + S64_A_BYTES + (wave * 4 + j) * 1024), 16, 0, 0);
+      sb[j] += BKM ? 2 * BK16 : 2 * BK16 * p.ldb;
+    }
+  };
+  if (mine > 0) issue(0);
+  if (mine > 1) issue(1);
+  int cur = 0;
+  for (int it = 0; it < nit; ++it) {
+    if (it + 1 < mine) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // (all eight waves: the two groups advance in lock-step)
+    if (it + 2 < mine) issue(cur >= 1 ? cur - 1 : 2);
+    if (it < mine) {
+      const char* la = ring + cur * S64_STAGE;
+      const char* lb = la + S64_A_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[2], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = load_frag16<true>(la, wr * 32 + i * 16, ks, lane);
+        load_frags4<BKM, false>(lb, wc * 64, ks, lane, bfr);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  __syncthreads();        // every wave is done with the rings; LDS becomes the exchange buffer + wave-private scratch
+  // wave (grp, wave) keeps rows 16 grp .. 16 grp + 15 of wave tile `wave`: it hands the OTHER 16 rows to its partner
+  float* xch = reinterpret_cast<float*>(smem);           // [8 waves][4 j][64 lanes] f32x4 = 32 KiB
+  {
+    f32x4* mine_out = reinterpret_cast<f32x4*>(xch) + ((size_t)wave8 * 4) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mine_out[j * 64] = grp ? acc[0][j] : acc[1][j];
+  }
+  __syncthreads();
+  f32x4 fin[4][4];
+  {
+    const f32x4* theirs = reinterpret_cast<const f32x4*>(xch) + ((size_t)(wave8 ^ 4) * 4) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 t = theirs[j * 64], o = grp ? acc[1][j] : acc[0][j];
+      fin[0][j] = (f32x4){o[0] + t[0], o[1] + t[1], o[2] + t[2], o[3] + t[3]};
+    }
+  }
+  __syncthreads();        // the exchange buffer is dead: wave-private epilogue scratch may overwrite it
+  wave_epilogue_rows<bf16_t, OutT, 0, 1>(p, fin, C, m0 + wr * 32 + grp * 16, n0 + wc * 64, lane,
+                                         reinterpret_cast<float*>(smem + wave8 * WEPI_Q_BYTES), true, p.alpha);
+}
+
+template <typename Kn>
+int launch_s64k2(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
+  g_last_kernel = "s64k2";
+  favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), S64K2_LDS);
+  hipLaunchKernelGGL(kernel, grid, dim3(S64K2_THREADS), S64K2_LDS, st, kp);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
 }
 
 template <typename Kn>
@@ -2121,7 +2244,7 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 // same result; the work-skipping probe switch (FAVIT_GEMM_DBG) exists only in the `make probe` build.
 struct GemmKnobs {
   int dbg, store_policy;
-  bool force128, no_p4, no_p7, no_s64, no_pp, no_quarter;
+  bool force128, no_p4, no_p7, no_s64, no_s64k2, no_pp, no_quarter;
   long quarter_max;
   GemmKnobs() {
     const char* e;
@@ -2135,6 +2258,7 @@ struct GemmKnobs {
     no_p4 = getenv("FAVIT_GEMM_NO_P4") != nullptr;
     no_p7 = getenv("FAVIT_GEMM_NO_P7") != nullptr;
     no_s64 = getenv("FAVIT_GEMM_NO_S64") != nullptr;
+    no_s64k2 = getenv("FAVIT_GEMM_NO_S64K2") != nullptr;
     no_pp = getenv("FAVIT_GEMM_NO_PP") != nullptr;
     no_quarter = getenv("FAVIT_GEMM_NO_QUARTER") != nullptr;
     quarter_max = (e = getenv("FAVIT_GEMM_QUARTER_MAX")) ? atol(e) : 128;       // tail rounds up to 25 % of the slots
@@ -2380,6 +2504,15 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
     const long tm = (g->M + S64_BM - 1) / S64_BM;
     ks.ntiles = (int)(tm * tiles_n);
     dim3 grids((unsigned)(tm * tiles_n), 1u, (unsigned)batch);
+    // no more tiles than CUs and at least four k-steps: the K loop split between two wave groups (s64k2)
+    if (!knobs().no_s64k2 && batch == 1 && tm * tiles_n <= 256 && g->K >= 4 * BK16) {
+      if (g->out_dtype == FAVIT_BF16) {
+        if (g->b_kmajor) return launch_s64k2(gemm_bf16_s64k2_kernel<true, bf16_t>, ks, grids, st);
+        return launch_s64k2(gemm_bf16_s64k2_kernel<false, bf16_t>, ks, grids, st);
+      }
+      if (g->b_kmajor) return launch_s64k2(gemm_bf16_s64k2_kernel<true, float>, ks, grids, st);
+      return launch_s64k2(gemm_bf16_s64k2_kernel<false, float>, ks, grids, st);
+    }
     if (g->out_dtype == FAVIT_BF16) {
       if (g->b_kmajor) return launch_s64(gemm_bf16_s64_kernel<true, bf16_t>, ks, grids, st);
       return launch_s64(gemm_bf16_s64_kernel<false, bf16_t>, ks, grids, st);

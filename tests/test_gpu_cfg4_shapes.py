@@ -135,7 +135,7 @@ def _base384(favit):
     return m, x, y
 
 
-@pytest.mark.parametrize("mode,tol_elem,tol_gn,tol_logits", [("bf16", 2e-3, 5e-2, 2e-2), ("fp8", 0.25, FP8_TOL["gnorm"], FP8_TOL["logits"])])
+@pytest.mark.parametrize("mode,tol_elem,tol_gn,tol_logits", [("bf16", 1.5e-2, 5e-2, 2e-2), ("fp8", 0.25, FP8_TOL["gnorm"], FP8_TOL["logits"])])
 def test_full_size_cfg4_forward_backward_matches_golden(favit, K, mode, tol_elem, tol_gn, tol_logits):
     """B = 64 forward + backward through bench.py's flow (flat gradient buffers, grouped weight gradients) == the
     B = 1 HIP result == the reference's golden run.  fp8: the B = 1 pass is every site's first call (it measures its

@@ -256,10 +256,15 @@ def _cfg2_model(favit):
     return m, x, y
 
 
-@pytest.mark.parametrize("mode,tol_elem,tol_gn,tol_logits", [("fp32", 2e-4, 2e-3, 1e-3), ("bf16", 2e-3, 5e-2, 2e-2)])
+@pytest.mark.parametrize("mode,tol_elem,tol_gn,tol_logits", [("fp32", 2e-4, 2e-3, 1e-3), ("bf16", 1.5e-2, 5e-2, 2e-2)])
 def test_full_size_cfg2_forward_backward_matches_golden(favit, K, mode, tol_elem, tol_gn, tol_logits):
     """B = 256 forward + backward through the fused-optimizer flow of bench.py (flat .grad buffers, direct
-    gradient accumulation, grouped weight-gradient launch) == the B = 2 result == the reference's golden run."""
+    gradient accumulation, grouped weight-gradient launch) == the B = 2 result == the reference's golden run.
+    bf16 element-wise tolerance: 1.5e-2 since round 4 -- the B = 2 pass (394 token rows) runs its N = 384 projections
+    in the split-K-inside-the-workgroup kernel (s64k2: even and odd k-steps summed separately), the B = 256 pass in the
+    256x128-tile kernel (one chain): the fp32 sums differ in the last bit, some bf16 roundings of the products flip, and
+    twelve layers later the gradients differ by 0.5-0.8 % (round 3: identical summation order in both kernels, 2e-3).
+    The fp32 mode (exact-fp32 kernels, one chain everywhere) keeps 2e-4."""
     favit.set_compute_dtype(mode)
     try:
         m, x, y = _cfg2_model(favit)

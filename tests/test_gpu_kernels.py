@@ -559,6 +559,38 @@ def test_layernorm_fused_gemm_declines_large_or_odd_shapes(K):
     assert K.ln_gemm(x, 320, torch.ones(320, device=DEV), torch.zeros(320, device=DEV), w, out, 256, 128, 320) is None
 
 
+@pytest.mark.parametrize("bk", [True, False])
+@pytest.mark.parametrize("M,N,Kd", [(128 * 17, 384, 384), (128 * 17, 384, 1152), (128 * 17, 384, 1536), (64 * 65, 192, 768),
+                                    (64 * 65, 192, 576), (128 * 17 - 13, 384, 320), (1000, 200, 256), (4160, 136, 1984)])
+@pytest.mark.parametrize("out_dtype,epi", [(torch.bfloat16, "plain"), (torch.bfloat16, "dgelu"), (torch.float32, "res")])
+def test_gemm_small_m_split_k_inside_the_workgroup(K, favit, bk, M, N, Kd, out_dtype, epi):
+    """s64k2: launches of the 64-row kernel with no more tiles than CUs run their K loop in two wave groups (even / odd
+    k-steps) and add the halves through LDS.  Against fp64 on bf16-rounded operands, even and odd k-step counts, ragged
+    M and N, both B layouts, the epilogues the short-token steps use; bitwise reproducible."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + Kd)
+    A = _rand((M, Kd), torch.bfloat16, g)
+    B = _rand((N, Kd) if bk else (Kd, N), torch.bfloat16, g)
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g) if epi == "res" else None
+    aux = _rand((M, N), torch.bfloat16, g) if epi == "dgelu" else None
+    outs = []
+    for _ in range(2):
+        C = torch.full((M, N), float("nan"), dtype=out_dtype, device=DEV)
+        K.gemm(A, B, C, M, N, Kd, Kd, B.stride(0), N, b_kmajor=bk, bias=bias, residual=res, ld_res=N,
+               act=favit._abi.ACT_DGELU if epi == "dgelu" else favit._abi.ACT_NONE, aux_in=aux, ld_aux_in=N)
+        assert favit._abi.lib().favit_gemm_last_kernel().decode() == "s64k2"
+        outs.append(C)
+    ref = A.double() @ (B.double().t() if bk else B.double()) + bias.double()
+    if epi == "dgelu":
+        u = aux.double()
+        ref = ref * (0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi))
+    if res is not None:
+        ref = ref + res.double()
+    assert torch.isfinite(outs[0].float()).all()
+    assert rel_l2(outs[0], ref) < (2e-5 if out_dtype == torch.float32 else 1e-2)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_zero_fills_survive_graph_replays(K):
     """The launches that zero a destination and then add into it with atomics (embed-prologue backward: cls_token /
     pos_embed gradients; latent_proj fold backward), captured ONCE in a HIP graph and replayed: every replay equals the
