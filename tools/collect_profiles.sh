@@ -5,7 +5,7 @@
 #   * separate PMC passes (never combined with a trace domain): FETCH_SIZE and WRITE_SIZE per configuration, folded by
 #     tools/pmc_traffic.py into HBM bytes per launch and per step; one SQ / GRBM pass for cfg2 (MFMA-pipe utilisation).
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 prof=$out/final   # (only gpurun_out/ travels back from the GPU box: copy prof_$tag/final/* into profiles/ afterwards)
@@ -47,8 +47,30 @@ run_stats cfg4_fp8 --config cfg4 --dtype fp8
 run_pmc cfg4_fp8 cfg4 fp8 --config cfg4 --dtype fp8
 run_stats cfg1 --config cfg1
 run_pmc cfg1 cfg1 bf16 --config cfg1
-run_stats cfg3 --config cfg3 --slic
+run_stats cfg3 --config cfg3
+run_stats cfg3_slic --config cfg3 --slic
 run_pmc cfg3 cfg3 bf16 --config cfg3
 run_stats cfg5 --config cfg5
 run_pmc cfg5 cfg5 bf16 --config cfg5
-ls -la $prof | tail -40
+# un-profiled bench lines of every configuration on this box (the default command first, with its CPU baseline)
+run_plain() {   # name, bench args...
+  local name=$1; shift
+  python3 $root/bench.py "$@" > $out/plain_$name.json 2> $out/plain_$name.err || echo "plain $name failed"
+  grep '^{' $out/plain_$name.json > $prof/${tag}_bench_unprofiled_$name.json || true
+  echo "[collect] plain $name done"
+}
+cd $root
+python3 $root/bench.py > $out/plain_default.json 2> $out/plain_default.err || echo "default run failed"
+grep '^{' $out/plain_default.json > $prof/${tag}_bench_default_run.json || true
+echo "[collect] default run done"
+run_plain cfg2 --config cfg2 --no-cpu-baseline
+run_plain cfg2_drop --config cfg2 --dropout 0.1 --no-cpu-baseline
+run_plain cfg2_drop_all --config cfg2 --dropout 0.1 --attn-dropout 0.1 --embed-dropout 0.1 --no-cpu-baseline
+run_plain cfg1 --config cfg1 --no-cpu-baseline
+run_plain cfg3 --config cfg3 --no-cpu-baseline
+run_plain cfg3_slic --config cfg3 --slic --no-cpu-baseline
+run_plain cfg5 --config cfg5 --no-cpu-baseline
+run_plain cfg4_bf16 --config cfg4 --no-cpu-baseline
+run_plain cfg4_fp8 --config cfg4 --dtype fp8 --no-cpu-baseline
+run_plain cfg2_fp32 --config cfg2 --dtype fp32 --steps 5 --warmup 2 --no-cpu-baseline
+ls -la $prof | tail -60

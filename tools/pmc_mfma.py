@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Fold a rocprofv3 SQ/GRBM PMC pass over tools/gemm_bench.py into per-kernel MFMA utilisation and
-wave-state shares.  usage: pmc_mfma.py <pmc_dir> <out.txt>
+"""Fold a rocprofv3 SQ/GRBM PMC pass (over `bench.py --steps 2 --warmup 1`, or over tools/gemm_bench.py) into per-kernel
+MFMA utilisation and wave-state shares of the GEMM kernels.  usage: pmc_mfma.py <pmc_dir> <out.txt>
   MFMA util      = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8
                    (rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs, MI355X_MICROARCH.md)
   wave states    = SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY as shares of SQ_WAVE_CYCLES"""
