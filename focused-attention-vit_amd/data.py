@@ -235,7 +235,11 @@ class DeviceLoader:
             x, maps = d_img
             x.record_stream(cs)
             maps.record_stream(cs)
-            self.segmenter.set_label_maps(maps)           # the model's next segment() call returns them
+            # the model's next segment() call returns them; a captured step reads the installed tensor in place
+            if getattr(self.segmenter, "_captured", False) and self.segmenter._maps is not None:
+                self.segmenter.update_label_maps(maps)
+            else:
+                self.segmenter.set_label_maps(maps)
             return x, d_lab
         d_img.record_stream(cs)
         return self.tf(d_img), d_lab

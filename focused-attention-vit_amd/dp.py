@@ -272,7 +272,7 @@ class GradSync:
             # making progress: a 4-rank run without this block hung in its third step with, on EVERY rank, the main
             # thread in wait() on the first bucket's handle, two threads in kfd_wait_on_events and two spinning on HSA
             # signals (gloo's workers inside their stream synchronise), the network thread idle in epoll
-            # (gpurun_out/hang_rank*.txt, bench.py FAVIT_BENCH_WATCHDOG).  So no device-side wait is created: an event
+            # (thread dumps of bench.py's FAVIT_BENCH_WATCHDOG).  So no device-side wait is created: an event
             # is recorded behind the bucket's last writer and the collective is issued only once that event has
             # completed (polled from this thread at every reported gradient: _Staged), from an otherwise idle stream
             # (gloo's own event is complete the moment it is recorded).  Buckets still go out while backward runs.  RCCL (one process per GPU, collectives ordered by

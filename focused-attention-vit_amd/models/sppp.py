@@ -28,11 +28,23 @@ class SuperpixelSegmentation:
         self.compactness = compactness
         self.sigma = sigma
         self._maps = None
+        self._captured = False         # a train.GraphedStep has captured the ADDRESS of the installed maps
         self.rescale_input = True      # scikit-image >= 0.19 rescales every image to [0, 1] first; False = < 0.19
 
     def set_label_maps(self, maps: Optional[torch.Tensor]):
-        """Install precomputed label maps [B,H,W] (int64) returned by the next segment() calls."""
+        """Install precomputed label maps [B,H,W] (int64) returned by the next segment() calls.  A train.GraphedStep
+        captured earlier keeps reading (and keeps alive) the tensor that was installed at ITS capture: to change what
+        such a step sees, use update_label_maps."""
         self._maps = maps
+
+    def update_label_maps(self, maps: torch.Tensor):
+        """Copy new label maps INTO the installed tensor (same shape): the form a captured training step needs, whose
+        replayed kernels read the installed tensor's address (data.DeviceLoader does this per batch once a step has
+        been captured)."""
+        if self._maps is None or tuple(maps.shape) != tuple(self._maps.shape) or maps.device != self._maps.device:
+            raise RuntimeError("update_label_maps: install maps of this shape with set_label_maps first")
+        if maps is not self._maps:
+            self._maps.copy_(maps.to(self._maps.dtype), non_blocking=True)
 
     def segment_device(self, images: torch.Tensor) -> torch.Tensor:
         """Device SLIC of a batch [B,3,H,W] on the current stream, ignoring installed maps (data.DeviceLoader calls it

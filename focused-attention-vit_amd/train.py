@@ -254,6 +254,16 @@ class GraphedStep:
         # the others (gradients handed to autograd: cls_token, pos_embed, ...) are counted with the last piece
         seen = {id(p) for lst in self._ready for p in lst}
         self._ready[-1].extend(p for g_ in opt.groups for p in g_["flat"].params if id(p) not in seen)
+        # Everything allocated OUTSIDE the graphs' pool whose address the captured kernels hold stays alive with the step:
+        # the optimizer's flat buffers and bf16 mirrors (self.opt), the dropout epoch and the inputs (self.epoch / x / y),
+        # the split-K slab workspace (kernels.py keeps outgrown ones) -- and the installed label maps (their content is
+        # changed with SuperpixelSegmentation.update_label_maps; data.DeviceLoader does so once a step is captured).
+        self._keep = [K._GROUPED_WS.get(self.x.device.index)]
+        for mod in model.modules():
+            seg = getattr(mod, "segmentation", None)
+            if seg is not None and getattr(seg, "_maps", None) is not None:
+                seg._captured = True
+                self._keep.append(seg._maps)
 
     def _forward_backward(self, graphs):
         """zero_grad + forward + loss, then backward piece by piece; with a list, every piece is captured in a graph of

@@ -132,6 +132,25 @@ def test_device_slic_on_mean_std_normalised_inputs(favit, rescale):
 
 
 @pytest.mark.gpu
+def test_device_slic_rescale_of_a_normalised_image_equals_its_unit_range_original(favit):
+    """What the min-max rescale is for: an image that spans [0, 1], normalised with ONE mean / std for all channels
+    (the reference's generic datasets: (x - 0.5) / 0.5), segments with rescale=True exactly as its original does with
+    rescale=False (the scikit-image < 0.19 form on [0, 1] data): same features up to one quantisation step, hence the
+    same integer stages downstream.  (With per-channel ImageNet statistics the normalisation is not a global affine
+    map and no such identity exists: that case has no parity target at all, INTEGRATION.md.)"""
+    K = favit.kernels
+    H = W = 96
+    img = _smooth_image(H, W, 7).astype(np.float32)
+    img = (img - img.min()) / (img.max() - img.min())                 # spans [0, 1] exactly
+    norm = (img - 0.5) / 0.5
+    _, f0, l0, _ = K.slic(torch.from_numpy(img[None]).to(DEV), n_segments=9, compactness=1.0, stages=True, rescale=False)
+    _, f1, l1, _ = K.slic(torch.from_numpy(norm[None]).to(DEV), n_segments=9, compactness=1.0, stages=True, rescale=True)
+    d = (f0.cpu().numpy().astype(np.int64) - f1.cpu().numpy().astype(np.int64))
+    assert np.abs(d).max() <= 1 and (d == 0).mean() > 0.98
+    assert (l0 == l1).float().mean().item() > 0.995                    # (a one-step feature difference can move a border pixel)
+
+
+@pytest.mark.gpu
 def test_device_slic_ground_truth_and_properties(favit):
     from scipy import ndimage
     K = favit.kernels
