@@ -1183,6 +1183,271 @@ __global__ __launch_bounds__(P4_THREADS, 4) void gemm_bf16_p4_kernel(KParams p) 
   p4_body<AK, BKM, OutT>(p, tile, split, blockIdx.z);
 }
 
+// --------------------------------------------------------------------------------------
+// bf16 kernel "pd" (EXPERIMENTAL, FAVIT_GEMM_PD=1): the 256x128 tile and the 64x64 wave tiles of p4 as ONE persistent
+// 8-wave workgroup per CU with a DEFERRED epilogue -- DESIGN.md section 7, item 1.  A workgroup walks its tiles; the
+// accumulators of tile t move to a second register set and are written out in four 16-row slices per wave BETWEEN the
+// k-steps of tile t + 1 (a wave slices every third k-step; the two waves of a SIMD never in the same step), while the
+// DMA ring (three 24-KiB stages) streams on across tile borders.
+//   vmcnt is ONE in-order counter for DMA pieces, loads and stores.  Every vector-memory operation of a wave is
+//   therefore counted (`issued`), every ring stage remembers the count at its issue (`marks`), and "stage g has landed"
+//   = at most (issued - mark[g]) younger operations outstanding.  Nothing is ever loaded into a compiler-managed
+//   register asynchronously: the epilogue's operands (residual rows, bias) travel by the same LDS-DMA as the GEMM
+//   operands, into wave-private buffers, one slice (three k-steps) ahead; its stores are inline asm (exact count).
+//   NT layout, M % 256 == 0, N % 128 == 0, K % 32 == 0, K >= 384.  EPI 0: bf16 out (+ bias); EPI 1: fp32 out + bias +
+//   fp32 residual.
+// --------------------------------------------------------------------------------------
+constexpr int PD_STAGES = 3;
+constexpr int PD_RING = PD_STAGES * P4_STAGE;             // 73728
+constexpr int PD_SCRATCH = 16 * WEPI_LD * 4;              // 4352 B: one 16-row slice of accumulators, transposed through LDS
+constexpr int PD_RBUF = 4096;                             // residual rows of the next slice: 4 DMA pieces [4 rows][64 fp32]
+constexpr int PD_BBUF = 1024;                             // bias of the tile: one DMA piece (16 chunks of 4 columns)
+constexpr int PD_WAVE = PD_SCRATCH + PD_RBUF + PD_BBUF;   // 9472
+constexpr int PD_LDS = PD_RING + 8 * PD_WAVE;             // 149504
+
+__device__ __forceinline__ void pd_wait(int younger) {
+  // until at most `younger` operations are outstanding, rounded DOWN to an available immediate (never too few)
+  if (younger >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (younger >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if (younger >= 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+  else if (younger >= 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else if (younger >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if (younger >= 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+  else if (younger >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (younger >= 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  else if (younger >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (younger >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if (younger >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (younger >= 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if (younger >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (younger >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if (younger >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (younger >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (younger >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if (younger >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// 16-byte non-temporal store as inline asm (exactly one vector-memory instruction; the data registers are read at
+// issue).  (An SGPR-base form -- "s"(base) + 32-bit lane offset -- faulted on a null base in the probe build of the
+// EPI 1 instantiation, which spills 49 SGPRs; the 64-bit VGPR pointer form is the one store16_policy uses.)
+__device__ __forceinline__ void pd_gstore16(void* base, unsigned off, const f32x4& v) {
+  void* ptr = reinterpret_cast<char*>(base) + off;
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(ptr), "v"(v) : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(P4_THREADS, 2) void gemm_bf16_pd_kernel(KParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ph = wave % 3;                               // this wave slices at k-steps ph, ph + 3, ph + 6, ph + 9
+  char* wbase = smem + PD_RING + wave * PD_WAVE;
+  float* wl = reinterpret_cast<float*>(wbase);
+  char* rbuf = wbase + PD_SCRATCH;
+  char* bbuf = rbuf + PD_RBUF;
+  const char* A = reinterpret_cast<const char*>(p.A);
+  const char* Bm = reinterpret_cast<const char*>(p.B);
+  const int nk = (int)(p.K / P4_BK);
+  const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+  const int my_tiles = (p.ntiles - bid + nwg - 1) / nwg;  // tiles bid, bid + nwg, ... (nwg % 8 == 0: all on this XCD's share)
+  typedef typename std::conditional<EPI == 0, bf16_t, float>::type OutT;
+  OutT* C = reinterpret_cast<OutT*>(p.C);
+
+  auto coords = [&](int ordinal, long& m0, long& n0) __attribute__((always_inline)) {
+    const int t = xcd_remap(bid + ordinal * nwg, p.ntiles);
+    m0 = (long)(t / p.tiles_n) * P4_BM;
+    n0 = (long)(t % p.tiles_n) * BN;
+  };
+
+  // ---- issue side of the ring: runs two stages ahead of the consumer, across tile borders ----
+  int issued = 0, islot = 0, is_tile = 0, is_k = 0;
+  unsigned long long marks = 0;   // three 16-bit fields: `issued` (mod 2^16) right after the DMA of the stage in ring slot 0..2
+  const char* sa[2];
+  const char* sb;
+  auto set_issue_tile = [&](int ordinal) __attribute__((always_inline)) {
+    long m0, n0;
+    coords(ordinal, m0, n0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      sa[j] = reinterpret_cast<const char*>(glds_src32<true>(reinterpret_cast<const bf16_t*>(A), p.lda, m0, p.M, 0, wave * 2 + j, lane));
+    sb = reinterpret_cast<const char*>(glds_src32<true>(reinterpret_cast<const bf16_t*>(Bm), p.ldb, n0, p.N, 0, wave, lane));
+  };
+  auto issue_one = [&]() __attribute__((always_inline)) {
+    if (is_tile < my_tiles) {                            // (uniform) else: nothing left to stream
+      char* st = smem + islot * P4_STAGE;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + (wave * 2 + j) * 1024), 16, 0, 0);
+        sa[j] += 64;
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + P4_A_BYTES + wave * 1024), 16, 0, 0);
+      sb += 64;
+      issued += 3;
+      const int sh = 16 * islot;                         // (scalar shifts on wave-uniform values: no array, no scratch)
+      marks = (marks & ~(0xFFFFull << sh)) | ((unsigned long long)(issued & 0xFFFF) << sh);
+      if (++is_k == nk) {
+        is_k = 0;
+        if (++is_tile < my_tiles) set_issue_tile(is_tile);
+      }
+    }
+    islot = islot == PD_STAGES - 1 ? 0 : islot + 1;      // (the slot advances even when nothing is issued: it mirrors the consumer)
+  };
+
+  // ---- deferred epilogue: accumulators and coordinates of the PREVIOUS tile; its operands arrive in rbuf / bbuf ----
+  f32x4 acc[4][4], prev[4][4];
+  long pm0 = 0, pn0 = 0;
+  // lane offsets (bytes) inside a slice: EPI 0: row lane / 8, columns 8 (lane % 8) .. of bf16; EPI 1: row lane / 16,
+  // columns 4 (lane % 16) .. of fp32 -- the uniform part (tile, wave, slice, row group) goes into the SGPR base
+  const unsigned loff_c = EPI == 0 ? (unsigned)(((lane >> 3) * p.ldc + 8 * (lane & 7)) * 2)
+                                   : (unsigned)(((lane >> 4) * p.ldc + 4 * (lane & 15)) * 4);
+  const long loff_r = ((long)(lane >> 4) * p.ld_res + 4 * (lane & 15)) * 4;
+  // residual rows of slice Q of the tile at (m0, n0) -> rbuf: piece `it` = rows 4 it .. 4 it + 3, lane -> its own 16 bytes
+  auto load_res = [&](long m0, long n0, int Q) __attribute__((always_inline)) {
+    if constexpr (EPI == 1) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const char* src = reinterpret_cast<const char*>(p.residual + (m0 + wr * 64 + Q * 16 + it * 4) * p.ld_res + n0 + wc * 64) + loff_r;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(rbuf + it * 1024), 16, 0, 0);
+      }
+      issued += 4;
+    }
+  };
+  // bias columns n0 + 64 wc .. + 63 -> bbuf: lane l brings chunk l % 16 (4 columns) to bbuf + 16 l
+  auto load_bias = [&](long n0) __attribute__((always_inline)) {
+    if (p.bias != nullptr) {
+      const char* src = reinterpret_cast<const char*>(p.bias + n0 + wc * 64 + 4 * (lane & 15));
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)bbuf, 16, 0, 0);
+      issued += 1;
+    }
+  };
+  auto slice = [&](auto qtag) __attribute__((always_inline)) {
+    constexpr int Q = decltype(qtag)::value;
+    // accumulators of rows 16 Q .. 16 Q + 15 -> wave-private LDS scratch (transposed reads below)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(wl + (lane & 15) * WEPI_LD + j * 16 + 4 * (lane >> 4)) = prev[Q][j];
+    // (same wave wrote and reads: the compiler's lgkmcnt wait orders them)
+    if constexpr (EPI == 0) {
+      f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (p.bias != nullptr) {
+        b0 = *reinterpret_cast<const f32x4*>(bbuf + 32 * (lane & 7));
+        b1 = *reinterpret_cast<const f32x4*>(bbuf + 32 * (lane & 7) + 16);
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + (lane >> 3), col = 8 * (lane & 7);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(wl + row * WEPI_LD + col);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(wl + row * WEPI_LD + col + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          o[c] = (bf16_t)fmaf(t0[c], p.alpha, b0[c]);
+          o[4 + c] = (bf16_t)fmaf(t1[c], p.alpha, b1[c]);
+        }
+        pd_gstore16(C + (pm0 + wr * 64 + Q * 16 + it * 8) * p.ldc + pn0 + wc * 64, loff_c, __builtin_bit_cast(f32x4, o));
+      }
+      issued += 2;
+    } else {
+      f32x4 b0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr) b0 = *reinterpret_cast<const f32x4*>(bbuf + 16 * (lane & 15));
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 4 + (lane >> 4), col = 4 * (lane & 15);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(wl + row * WEPI_LD + col);
+        const f32x4 r = *reinterpret_cast<const f32x4*>(rbuf + it * 1024 + 16 * lane);
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = fmaf(t[c], p.alpha, b0[c]) + r[c];
+        pd_gstore16(C + (pm0 + wr * 64 + Q * 16 + it * 4) * p.ldc + pn0 + wc * 64, loff_c, o);
+      }
+      issued += 4;
+      // (every read of rbuf has been consumed by a store above: the next slice's rows may land in it)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (Q < 3) load_res(pm0, pn0, Q + 1);              // the next slice's residual rows: three k-steps of lead
+    }
+  };
+  auto slice_n = [&](int j) __attribute__((always_inline)) {
+    if (j == 0) slice(std::integral_constant<int, 0>());
+    else if (j == 1) slice(std::integral_constant<int, 1>());
+    else if (j == 2) slice(std::integral_constant<int, 2>());
+    else slice(std::integral_constant<int, 3>());
+  };
+
+  set_issue_tile(0);
+  issue_one();
+  issue_one();
+  int cslot = 0;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    long m0, n0;
+    coords(ti, m0, n0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nk; ++k) {
+      // this wave's pieces of the stage in slot cslot have landed: at most (issued - mark) younger operations in flight
+      pd_wait((issued - (int)((marks >> (16 * cslot)) & 0xFFFF)) & 0xFFFF);
+      __builtin_amdgcn_s_barrier();                      // ... everybody's; and everybody is done with the previous stage
+#ifdef FAVIT_PROBE
+      const bool no_epi = (p.dbg & 0x10000) != 0;         // probe build: no slices, no epilogue operands (timing only)
+#else
+      constexpr bool no_epi = false;
+#endif
+      if (ti > 0 && !no_epi) {
+        const int d = k - ph;
+        if (d >= 0 && d < 12 && d % 3 == 0) slice_n(d / 3);
+      }
+      if (k == nk - 3 + ph && !no_epi) {                 // operands of THIS tile's first slice (runs in the next tile's step ph,
+        load_bias(n0);                                   // or in the drain): the previous tile's last slice has read both buffers
+        load_res(m0, n0, 0);
+      }
+      issue_one();                                       // two stages ahead, into the slot of the stage consumed last
+      const char* st = smem + cslot * P4_STAGE;
+      bf16x8 af[4], bfr[4];
+      load_frags4<true, true>(st, wr * 64, 0, lane, af);
+      load_frags4<true, true>(st + P4_A_BYTES, wc * 64, 0, lane, bfr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      cslot = cslot == PD_STAGES - 1 ? 0 : cslot + 1;
+    }
+    // tile border: the finished accumulators become the deferred epilogue's input
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) prev[i][j] = acc[i][j];
+    pm0 = m0; pn0 = n0;
+  }
+  // drain: the last tile's epilogue, nothing left to overlap it with
+#ifdef FAVIT_PROBE
+  if (p.dbg & 0x10000) {                                  // (keeps the accumulators alive)
+    float sres = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sres += prev[i][j][0] + prev[i][j][1] + prev[i][j][2] + prev[i][j][3];
+    if (sres == 12345.678f) C[0] = (OutT)sres;
+    return;
+  }
+#endif
+  for (int j = 0; j < 4; ++j) {
+    pd_wait(0);
+    slice_n(j);
+  }
+  pd_wait(0);
+}
+
+template <typename Kn>
+int launch_pd(Kn kernel, const KParams& kp, int nwg, hipStream_t st) {
+  g_last_kernel = "pd";
+  favit_ensure_dyn_lds(reinterpret_cast<const void*>(kernel), PD_LDS);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nwg), dim3(P4_THREADS), PD_LDS, st, kp);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
 // fp8 operands (F8 = 1: e4m3 x e4m3, 2: e5m2 A x e4m3 B), NT layout only
 template <typename OutT, int F8>
 __global__ __launch_bounds__(P4_THREADS, 4) void gemm_fp8_p4_kernel(KParams p) {
@@ -2463,6 +2728,24 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
     }
     if (g->b_kmajor) return launch_pp(gemm_bf16_pp_kernel<true, float>, kp, gridp, st);
     return launch_pp(gemm_bf16_pp_kernel<false, float>, kp, gridp, st);
+  }
+  // experimental persistent kernel with the deferred epilogue (FAVIT_GEMM_PD=1; read per call: tests toggle it)
+  if (glds_ok && !force128 && splits == 1 && !atomic && batch == 1 && g->a_kmajor && g->b_kmajor && !g->a_rowsum &&
+      (g->M % P4_BM) == 0 && (g->N % BN) == 0 && (g->K % P4_BK) == 0 && g->K >= 12 * P4_BK && t4 >= 8 &&
+      g->act == FAVIT_ACT_NONE && !g->aux_out && !g->aux_in && kp.drop_thresh == 0 && kp.c_vec && getenv("FAVIT_GEMM_PD") != nullptr) {
+    const bool res_f32 = g->out_dtype == FAVIT_F32 && g->residual != nullptr;
+    const bool plain_bf16 = g->out_dtype == FAVIT_BF16 && g->residual == nullptr;
+    if (res_f32 || plain_bf16) {
+      KParams kd = kp;
+      kd.ntiles = (int)t4;
+      int ncu = 256;
+      { const char* e = getenv("FAVIT_GEMM_PD_WGS"); if (e && atoi(e) >= 8 && atoi(e) <= 512) ncu = atoi(e) & ~7; }
+      const int nwg = t4 < ncu ? (int)(t4 & ~7L) : ncu;
+      if (nwg >= 8) {
+        if (res_f32) return launch_pd(gemm_bf16_pd_kernel<1>, kd, nwg, st);
+        return launch_pd(gemm_bf16_pd_kernel<0>, kd, nwg, st);
+      }
+    }
   }
   if (glds_ok && !force128 && !no_p4 && (g->K % P4_BK) == 0 && (kps % P4_BK) == 0 &&
       ((splits == 1 && g->M >= 1024 && t4 * batch >= 256) || (xcd_split && splits > 1))) {

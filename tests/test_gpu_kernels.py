@@ -591,6 +591,40 @@ def test_gemm_small_m_split_k_inside_the_workgroup(K, favit, bk, M, N, Kd, out_d
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("wgs", ["8", "64", "256"])
+@pytest.mark.parametrize("M,N,Kd", [(2048, 384, 384), (4096, 1152, 384), (8192, 384, 1536), (50432, 384, 384), (50432, 384, 1536)])
+@pytest.mark.parametrize("epi", ["bf16_bias", "bf16_plain", "f32_res"])
+def test_gemm_persistent_deferred_epilogue_kernel(K, favit, monkeypatch, wgs, M, N, Kd, epi):
+    """The experimental persistent kernel (FAVIT_GEMM_PD=1: one 8-wave workgroup per CU walks its tiles, the epilogue of
+    tile t runs in slices between the k-steps of tile t + 1, every memory operation counted for the ring's waits):
+    BITWISE equal to the 256x128-tile kernel (same accumulation chain per element, same epilogue arithmetic), for 1 to
+    many tiles per workgroup (FAVIT_GEMM_PD_WGS), with and without bias / residual."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + Kd)
+    A = _rand((M, Kd), torch.bfloat16, g)
+    B = _rand((N, Kd), torch.bfloat16, g)
+    bias = torch.randn(N, device=DEV, generator=g) if epi != "bf16_plain" else None
+    res = torch.randn(M, N, device=DEV, generator=g) if epi == "f32_res" else None
+    odt = torch.float32 if epi == "f32_res" else torch.bfloat16
+    ref = torch.full((M, N), float("nan"), dtype=odt, device=DEV)
+    K.gemm(A, B, ref, M, N, Kd, Kd, Kd, N, bias=bias, residual=res, ld_res=N)
+    base = favit._abi.lib().favit_gemm_last_kernel().decode()
+    monkeypatch.setenv("FAVIT_GEMM_PD", "1")
+    monkeypatch.setenv("FAVIT_GEMM_PD_WGS", wgs)
+    out = torch.full((M, N), float("nan"), dtype=odt, device=DEV)
+    K.gemm(A, B, out, M, N, Kd, Kd, Kd, N, bias=bias, residual=res, ld_res=N)
+    assert favit._abi.lib().favit_gemm_last_kernel().decode() == "pd"
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    r64 = A.double() @ B.double().t()
+    if bias is not None:
+        r64 = r64 + bias.double()
+    if res is not None:
+        r64 = r64 + res.double()
+    assert rel_l2(out, r64) < (2e-5 if odt == torch.float32 else 1e-2)
+    if base in ("p4", "s64", "s64k2") and base != "s64k2":
+        assert torch.equal(out, ref), f"differs from the {base} kernel"
+
+
 def test_zero_fills_survive_graph_replays(K):
     """The launches that zero a destination and then add into it with atomics (embed-prologue backward: cls_token /
     pos_embed gradients; latent_proj fold backward), captured ONCE in a HIP graph and replayed: every replay equals the
