@@ -40,6 +40,7 @@ def _check(j, steps, warmup, dtype="bf16"):
 
 
 @pytest.mark.parametrize("cfg,extra", [("cfg2", ["--batch", "16"]), ("cfg2", ["--batch", "16", "--dropout", "0.1"]),
+                                       ("cfg2", ["--batch", "16", "--dropout", "0.1", "--attn-dropout", "0.1", "--embed-dropout", "0.1"]),
                                        ("cfg1", []), ("cfg3", ["--batch", "16"]), ("cfg3", ["--batch", "16", "--slic"]),
                                        ("cfg5", ["--batch", "16"]), ("cfg2", ["--batch", "16", "--dtype", "fp32"]),
                                        ("cfg4", ["--batch", "2", "--dtype", "fp8"])])
@@ -52,7 +53,10 @@ def test_bench_line(cfg, extra):
     if cfg == "cfg5":
         assert j["config"]["hip_graph"] is True and "R = 16 / R = 15" in j["config"]["workload"]
     if "--dropout" in extra:
+        # the reference's setting is dropout 0.1 with attn / embed dropout 0.0 (main.py:106-111): --dropout sets only the first
         assert j["config"]["dropout"] == 0.1
+        want = 0.1 if "--attn-dropout" in extra else 0.0
+        assert j["config"]["attn_dropout"] == want and j["config"]["embed_dropout"] == want
 
 
 def test_bench_refuses_to_report_a_non_finite_run(tmp_path):

@@ -121,6 +121,51 @@ def test_device_loader_prefetches_label_maps_for_the_sppp_models(favit):
 
 
 @pytest.mark.gpu
+def test_device_loader_label_maps_reach_a_captured_step(favit):
+    """DeviceLoader(segmenter=...) + train.GraphedStep: the replayed kernels read the label-map tensor that was installed
+    at capture, so once a step is captured the loader COPIES each batch's maps into it (update_label_maps).  The loss of
+    the replayed step on (images, maps) of every yielded batch equals the eager model's on the same images and maps."""
+    D = favit.data
+    favit.set_compute_dtype("bf16")
+    try:
+        torch.manual_seed(5)
+        mk = lambda: favit.models.sppp_mhla.SPPPViTMHLA(img_size=64, patch_size=8, num_classes=10, embed_dim=64, depth=2, num_heads=4,
+                                                        num_superpixels=4, pooling_type="mean", window_size=3, use_mhla=True).to(DEV).train()
+        m, ref = mk(), mk()
+        ref.load_state_dict(m.state_dict())
+        # 2 x 2 blocks of flat colour: SLIC finds exactly the four quadrants (4 superpixel tokens per image), whatever the colours
+        rs = np.random.RandomState(9)
+        def batch():
+            q = rs.randint(30, 226, size=(8, 2, 2, 3)).astype(np.uint8)
+            return np.kron(q, np.ones((1, 32, 32, 1), dtype=np.uint8)), rs.randint(0, 10, size=8)
+        batches = [batch() for _ in range(4)]
+        tf = D.DeviceTransform("resize", 64, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+        for mm in (m, ref):
+            mm.segmentation.compactness = 10.0
+            mm.assume_num_tokens = 4
+        opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=0.0), lr=0.0, weight_decay=0.0, distributed=False)
+        ropt = favit.train.FusedAdamW(favit.train.param_groups(ref, lr=0.0), lr=0.0, weight_decay=0.0, distributed=False)
+        x0 = tf(torch.from_numpy(batches[0][0]).to(DEV))
+        y0 = torch.from_numpy(batches[0][1]).to(DEV)
+        m.segmentation.set_label_maps(m.segmentation.segment_device(x0))
+        step = favit.train.GraphedStep(m, opt, x0, y0)
+        assert m.segmentation._captured
+        installed = m.segmentation._maps
+        losses = []
+        for x, y in D.DeviceLoader(batches, tf, segmenter=m.segmentation):
+            assert m.segmentation._maps is installed                   # updated in place, never re-bound
+            got = step(x, y).item()
+            ref.segmentation.set_label_maps(ref.segmentation.segment_device(x))
+            want = favit.train.train_step(ref, x, y, ropt).item()
+            assert abs(got - want) < 2e-3 * max(1.0, abs(want)), (got, want)
+            losses.append(got)
+        assert len(set(round(v, 4) for v in losses)) > 1              # the batches (and their maps) really differ
+    finally:
+        favit.set_compute_dtype("fp32")
+        favit.functional.clear_lp_mirrors()
+
+
+@pytest.mark.gpu
 def test_harness_epoch_loop_and_measurements(favit, tmp_path):
     """fit / evaluate / measure_* on a tiny model and a synthetic uint8 dataset: the loss goes down, the result row
     has the reference's columns (experiments/mhla_pretrained.py:486-525), timers return positive device times."""
