@@ -32,6 +32,9 @@ run_pmc() {     # name, config, dtype, bench args...
   rm -rf $out/pmc_fetch_$name $out/pmc_write_$name
   echo "[collect] pmc $name done"
 }
+# PLAIN_ONLY=1: only the un-profiled lines (after the PMC files of this tag have been copied into profiles/: the lines
+# then carry `traffic_stale: false` against them)
+if [ -z "$PLAIN_ONLY" ]; then
 run_stats cfg2 --config cfg2
 run_pmc cfg2 cfg2 bf16 --config cfg2
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
@@ -52,6 +55,7 @@ run_stats cfg3_slic --config cfg3 --slic
 run_pmc cfg3 cfg3 bf16 --config cfg3
 run_stats cfg5 --config cfg5
 run_pmc cfg5 cfg5 bf16 --config cfg5
+fi
 # un-profiled bench lines of every configuration on this box (the default command first, with its CPU baseline)
 run_plain() {   # name, bench args...
   local name=$1; shift
