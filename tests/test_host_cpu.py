@@ -48,6 +48,51 @@ def test_gemm_descriptor_layout_matches_header(favit):
             assert getattr(favit._abi.GemmDesc, f).offset == int(off), f
 
 
+def _wgrad_descs(favit, T, D, nblocks):
+    """favit_gemm_t descriptors of the weight-gradient problems of `nblocks` blocks (fc2, fc1, proj, folded qkv); the
+    pointers are never dereferenced by the planning query (any aligned non-null value)."""
+    G = favit._abi.GemmDesc
+    shapes = [(D, 4 * D), (4 * D, D), (D, D), (3 * D, D)]
+    arr = (G * (4 * nblocks))()
+    i = 0
+    for _ in range(nblocks):
+        for N, Kd in shapes:
+            d = arr[i]
+            d.A = d.B = d.C = 0x10000
+            d.M, d.N, d.K = N, Kd, T
+            d.lda, d.ldb, d.ldc = N, Kd, Kd
+            d.batch = d.batch_inner = 1
+            d.in_dtype, d.out_dtype = favit._abi.BF16, favit._abi.F32
+            d.alpha = 1.0
+            d.accumulate = 1
+            i += 1
+    return arr, sum(n * k + n for n, k in shapes) * nblocks
+
+
+@pytest.mark.parametrize("name,T,D,nblocks,want_splits", [
+    ("cfg2, one block per launch", 256 * 197, 384, 1, 8),
+    ("cfg2, four blocks per launch", 256 * 197, 384, 4, 8),      # splits of <= 6,400 tokens: long splits drift (DESIGN.md section 4)
+    ("cfg4, one block per launch", 64 * 577, 768, 1, 8),
+    ("cfg3, the whole encoder", 128 * 17, 384, 12, 1),           # 756 tiles: no split, no slabs, no reduction kernel
+    ("cfg3, a graph segment of four blocks", 128 * 17, 384, 4, None),
+    ("cfg5 second bucket, the whole encoder", 128 * 16, 384, 12, 1),
+])
+def test_grouped_weight_gradient_plan_on_the_host(favit, name, T, D, nblocks, want_splits):
+    """The split count of the grouped weight-gradient launch is host logic (csrc/gemm.hip: grouped_plan -- chunks of
+    <= 64 tiles, units packed into eight per-XCD queues, a cost model): favit_gemm_grouped_tn_workspace returns
+    nsplit x slab bytes, or 0 when one split suffices and the tiles write dW themselves.  No GPU needed."""
+    lib = favit._abi.lib()
+    arr, out_floats = _wgrad_descs(favit, T, D, nblocks)
+    ws = int(lib.favit_gemm_grouped_tn_workspace(arr, len(arr)))
+    slab = (out_floats + 63) // 64 * 64 * 4                      # per problem [M, N] + [M] rounded to 4, the total to 64 floats
+    assert ws % slab == 0, (name, ws, slab)
+    splits = ws // slab if ws else 1
+    assert 1 <= splits <= 32
+    if want_splits is not None:
+        assert splits == want_splits, (name, splits)
+    assert int(lib.favit_gemm_grouped_tn_workspace(arr, 49)) == 0           # more than 48 problems: not one launch
+
+
 def test_cfg2_model_init_parity_and_state_dict_keys(favit):
     """Same RNG call order as the reference: same seed -> same weights."""
     torch.manual_seed(1234)
