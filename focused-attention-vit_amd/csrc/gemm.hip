@@ -2,14 +2,10 @@
 //
 //   C[m,n] = epilogue( alpha * sum_k A[m,k] * B[n,k] )
 //
-// The bf16 kernels share the fragment / epilogue code below:
+// Three bf16 kernels share the fragment / epilogue code below:
 //   * "p4" (the hot one): 256x128 tile, 8 waves, BK = 32, three LDS stages filled by
 //     global_load_lds with a counted vmcnt, wave-private transpose epilogue, 2 workgroups per CU;
-//     also runs the grouped / XCD-affine split-K weight-gradient launch (up to 48 problems per grid)
-//   * "p7" (256x256, 16 waves), "pp" (ping-pong, 12 waves): large NT / long-K problems
-//   * "s64" / "s64k2": 64x128 tiles for small M; s64k2 splits the K loop between two wave groups
-//   * "s64ln": LayerNorm fused into the A staging of s64 (favit_ln_gemm; at parity, not used by default)
-//   * "pd": persistent workgroup with a deferred epilogue (experimental, FAVIT_GEMM_PD=1; at parity, slower)
+//     also runs the grouped / XCD-affine split-K weight-gradient launch
 //   * "glds": 128x128 tile, direct-to-LDS double buffer (small and batched problems)
 //   * the register-staged 128x128 kernel (any shape / alignment; the fallback)
 // and one exact-fp32 kernel (the parity mode).  In the 128x128 kernels a 256-thread workgroup
