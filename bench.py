@@ -288,6 +288,8 @@ def main():
     ap.add_argument("--attn-dropout", type=float, default=0.0, help="`attn_dropout` (reference default 0.0, main.py:108)")
     ap.add_argument("--embed-dropout", type=float, default=0.0, help="`embed_dropout` (reference default 0.0, main.py:110)")
     ap.add_argument("--bucket-mb", type=float, default=0.0, help="all-reduce bucket size in MiB (default: dp.GradSync's own choice)")
+    ap.add_argument("--slic-cus", type=int, default=None,
+                    help="--slic: CUs the side stream of the overlapped segmentation may use (default: DeviceLoader's)")
     ap.add_argument("--slic", action="store_true",
                     help="cfg3: also time the step WITH the device SLIC inside it (label maps recomputed from the batch every "
                          "step instead of installed once); reported as `slic_inclusive`, never as `value`")
@@ -469,28 +471,36 @@ def main():
                             "superpixel-token count of synthetic images is not 16 for every image: the replayed graph "
                             "was captured for 16 tokens and the timing, not the loss, is what this line reports"}
         # the same with the SLIC of batch i + 1 on a side stream under step i (what a prefetching loader does)
-        side = torch.cuda.Stream()
-        main = torch.cuda.current_stream()
-        ready, used = torch.cuda.Event(), torch.cuda.Event()
-        nxt = K.slic(simg, n_segments=16, compactness=10.0)
-        ready.record(main)
-        sync()
-        ts0 = time.perf_counter()
-        for _ in range(args.steps):
-            main.wait_event(ready)
-            segs.copy_(nxt)
-            nxt.record_stream(main)
-            used.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(used)
-                nxt = K.slic(simg, n_segments=16, compactness=10.0)
-                ready.record(side)
-            step()
-        sync()
-        ts = time.perf_counter() - ts0
+        slic_cus = args.slic_cus if args.slic_cus is not None else pkg.data.SEGMENTER_CUS
+        side = pkg.streams.cu_masked_stream(slic_cus)
+        # a CU-masked stream is a BLOCKING stream (the API has no flag): it synchronises with the null stream in both
+        # directions, so the step of this leg runs on a stream of torch's pool instead of the default one
+        main = torch.cuda.Stream()
+        main.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(main):
+            ready, used = torch.cuda.Event(), torch.cuda.Event()
+            nxt = K.slic(simg, n_segments=16, compactness=10.0)
+            ready.record(main)
+            step()                                            # first replay on this stream outside the timed region
+            sync()
+            ts0 = time.perf_counter()
+            for _ in range(args.steps):
+                main.wait_event(ready)
+                segs.copy_(nxt)
+                nxt.record_stream(main)
+                used.record(main)
+                step()                                        # the step first: its launch must not queue behind the
+                with torch.cuda.stream(side):                 # host side of the ~40 segmentation launches
+                    side.wait_event(used)
+                    nxt = K.slic(simg, n_segments=16, compactness=10.0)
+                    ready.record(side)
+            sync()
+            ts = time.perf_counter() - ts0
+        torch.cuda.current_stream().wait_stream(main)
         slic_inc["overlapped"] = {"images_per_sec": round(world * B * args.steps / ts, 2),
                                   "ms_per_step": round(1e3 * ts / args.steps, 3),
-                                  "what": "SLIC of the next batch on a side stream while the step of this one runs"}
+                                  "side_stream_cus": slic_cus,
+                                  "what": "SLIC of the next batch on a CU-masked side stream while the step of this one runs"}
 
     # per-launch GEMM timing: two extra EAGER steps after the timed region (events cannot be captured in a graph).
     # Every rank runs them (the all-reduce inside opt.step() is collective); only rank 0 records events.

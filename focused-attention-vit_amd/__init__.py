@@ -15,6 +15,6 @@ from .functional import (get_compute_dtype, get_compute_mode, set_compute_dtype,
                          invalidate_weight_cache)
 from . import kernels, functional, models
 from . import dp, train
-from . import data, harness
+from . import data, harness, streams
 
 __all__ = ["set_compute_dtype", "get_compute_dtype", "get_compute_mode", "invalidate_weight_cache", "kernels", "functional", "models", "dp", "train", "data", "harness", "_abi"]

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, Iterable, Iterator, Optional, Sequence, Tuple
 
 import numpy as np
@@ -20,6 +21,11 @@ import torch
 
 from . import _abi
 from . import kernels as K
+from . import streams
+
+# CUs the loader's segmentation stream may occupy (of 256; read once).  Measured at the cfg3 batch (bench.py --config
+# cfg3 --slic --slic-cus N): see DESIGN.md, round 4.
+SEGMENTER_CUS = int(os.environ.get("FAVIT_SEGMENTER_CUS", "128"))
 
 CIFAR10_MEAN, CIFAR10_STD = (0.4914, 0.4822, 0.4465), (0.2470, 0.2435, 0.2616)
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
@@ -162,12 +168,21 @@ class DeviceLoader:
         """segmenter (optional): a models.sppp.SuperpixelSegmentation (``model.segmentation`` of the SPPP models).  The
         label maps of batch k+1 are then computed by the device SLIC on the loader's preparation stream while the
         consumer trains on batch k, and installed (``set_label_maps``) when the batch is yielded -- the reference
-        segments inside forward (models/sppp_mhla.py:278), on the critical path of every step."""
+        segments inside forward (models/sppp_mhla.py:278), on the critical path of every step.
+
+        The preparation stream is confined to ``SEGMENTER_CUS`` compute units; such a stream is a BLOCKING stream (the HIP
+        call has no flag), i.e. it synchronises with the default (null) stream in both directions.  A consumer that
+        wants the overlap therefore runs its step under ``with torch.cuda.stream(loader.compute_stream):`` (a stream
+        of torch's non-blocking pool; cfg3 batch: 3.38 ms per step + segmentation against 4.07 ms back to back); on
+        the default stream the results are the same and the two simply run one after the other."""
         self.src, self.tf = host_batches, transform
         self.dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         self.segmenter = segmenter
-        self.prep_stream = torch.cuda.Stream(device=self.dev) if segmenter is not None else None
+        # the segmentation stream is confined to SEGMENTER_CUS compute units (streams.py): its grids would otherwise
+        # fill every CU and the consumer's short launches would queue behind them
+        self.prep_stream = streams.cu_masked_stream(SEGMENTER_CUS, self.dev) if segmenter is not None else None
+        self.compute_stream = torch.cuda.Stream(device=self.dev) if segmenter is not None else None
         self._pin = [None, None]
 
     def __len__(self):

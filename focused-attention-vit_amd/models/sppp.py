@@ -184,6 +184,63 @@ def sppp_tokens(model, x: torch.Tensor) -> torch.Tensor:
     return model.pos_embed(t, cent)
 
 
+class TokenBucketed(nn.Module):
+    """Runs an SPPP model on batches whose images segment into DIFFERENT numbers of superpixel tokens.
+
+    The reference stacks the per-image token lists (``torch.stack``, models/sppp_mhla.py:300; models/sppp.py:446), so a
+    batch trains there only when every image happens to yield the same count -- SLIC on photographs does not promise
+    that.  (Its positional encoding, models/sppp.py:299, accepts exactly two counts per model: ``num_superpixels`` and
+    ``num_superpixels - 1``; other counts fail there for a batch of one as well, and they do here.)
+    This wrapper (an extension: nothing in the reference corresponds to it) groups the images of a batch by count,
+    runs the wrapped model once per group on that group's images and label maps, and returns the logits in the batch's
+    order; the pieces are joined with autograd-visible ops, so ONE ``loss.backward()`` on the whole batch's loss gives
+    the wrapped model's parameters exactly the gradients of that loss.  Per image the result is what the wrapped model
+    (and the reference) gives for that image alone.  One host sync per forward (the counts); eager steps only --
+    ``train.GraphedStep`` needs fixed shapes (bench.py's cfg5 captures one step per count instead).
+
+    ``parameters()``, ``state_dict()`` (prefix ``model.``), ``train()`` / ``eval()`` behave as for any module; hand the
+    WRAPPED model to ``train.param_groups`` / checkpoints if the reference's key names matter."""
+
+    def __init__(self, model: nn.Module):
+        super().__init__()
+        if not hasattr(model, "segmentation") or not hasattr(model, "patch_mapper"):
+            raise TypeError("TokenBucketed wraps the SPPP models (SPPPViT, SPPPViTMHLA, ...)")
+        self.model = model
+
+    @property
+    def segmentation(self):
+        return self.model.segmentation
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        m = self.model
+        seg_host = m.segmentation
+        maps = seg_host.segment(x)
+        if maps.device != x.device:
+            maps = maps.to(x.device)
+        counts = m.patch_mapper.map_patches_batched(maps)[1].tolist()           # the host sync
+        groups = {}
+        for i, c in enumerate(counts):
+            groups.setdefault(int(c), []).append(i)
+        installed, assumed = seg_host._maps, getattr(m, "assume_num_tokens", None)
+        if seg_host._captured:
+            raise RuntimeError("TokenBucketed: the wrapped model's label maps are captured by a GraphedStep")
+        try:
+            if len(groups) == 1:
+                seg_host._maps, m.assume_num_tokens = maps, next(iter(groups))
+                return m(x)
+            order, outs = [], []
+            for c in sorted(groups):
+                idx = torch.tensor(groups[c], device=x.device, dtype=torch.int64)
+                seg_host._maps, m.assume_num_tokens = maps.index_select(0, idx), c
+                outs.append(m(x.index_select(0, idx)))
+                order += groups[c]
+            inv = torch.empty(len(order), dtype=torch.int64)
+            inv[torch.tensor(order)] = torch.arange(len(order))
+            return torch.cat(outs, 0).index_select(0, inv.to(x.device))
+        finally:
+            seg_host._maps, m.assume_num_tokens = installed, assumed
+
+
 def calculate_superpixel_centroids(model, segmentation_maps: torch.Tensor) -> torch.Tensor:
     return K.sppp_centroids(segmentation_maps, model.num_superpixels)
 

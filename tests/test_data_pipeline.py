@@ -93,11 +93,43 @@ def test_device_loader_matches_direct_transform_and_overlaps(favit):
 
 
 @pytest.mark.gpu
-def test_device_loader_prefetches_label_maps_for_the_sppp_models(favit):
+def test_cu_masked_stream(favit):
+    """streams.cu_masked_stream: the stream carries the requested CU mask (read back through hipExtStreamGetCUMask),
+    kernels launched on it give the results of the default stream (device SLIC: bit-exact integers), and asking for
+    every CU returns an ordinary stream."""
+    import ctypes as C
+    S = favit.streams
+    total = torch.cuda.get_device_properties(0).multi_processor_count
+    s = S.cu_masked_stream(64)
+    words = (total + 31) // 32
+    back = (C.c_uint32 * words)()
+    hip = S._hip()
+    hip.hipExtStreamGetCUMask.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    assert hip.hipExtStreamGetCUMask(C.c_void_p(s.cuda_stream), words, back) == 0
+    assert sum(bin(w).count("1") for w in back) == 64
+    g = torch.Generator(device=DEV).manual_seed(11)
+    low = torch.rand(4, 3, 8, 8, device=DEV, generator=g)
+    img = torch.nn.functional.interpolate(low, size=(64, 64), mode="bicubic").contiguous()
+    want = favit.kernels.slic(img, n_segments=16, compactness=10.0)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        got = favit.kernels.slic(img, n_segments=16, compactness=10.0)
+    s.synchronize()
+    assert torch.equal(got, want)
+    assert not isinstance(S.cu_masked_stream(total), torch.cuda.ExternalStream)
+    with pytest.raises(ValueError):
+        S.cu_masked_stream(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("on_compute_stream", [False, True])
+def test_device_loader_prefetches_label_maps_for_the_sppp_models(favit, on_compute_stream):
     """DeviceLoader(segmenter=model.segmentation): the device SLIC of batch k+1 runs on the loader's preparation stream
     under the consumer's work on batch k; when a batch is yielded its label maps are installed, i.e. the model's
     segment() call (reference: inside forward, models/sppp_mhla.py:278) returns exactly what segmenting the yielded
-    images directly gives."""
+    images directly gives.  The consumer on the default stream (the CU-masked preparation stream then runs in turn with
+    it) and on ``loader.compute_stream`` (where the two overlap)."""
+    import contextlib
     D = favit.data
     rs = np.random.RandomState(3)
     low = rs.randint(0, 256, size=(4, 8, 7, 7, 3), dtype=np.uint8)                  # blocky images: clear regions
@@ -106,16 +138,19 @@ def test_device_loader_prefetches_label_maps_for_the_sppp_models(favit):
     seg = favit.models.sppp.SuperpixelSegmentation(num_segments=16, compactness=10.0)
     loader = D.DeviceLoader(batches, tf, segmenter=seg)
     n = 0
-    for (x, y), (hi, hl) in zip(loader, batches):
-        ref_x = tf(torch.from_numpy(hi).to(DEV))
-        assert torch.equal(x, ref_x) and torch.equal(y.cpu(), torch.from_numpy(hl))
-        got = seg.segment(x)                                         # what the model's forward would receive
-        # (busy work on the consumer stream while the loader's next batch is being segmented on its own stream)
-        _ = (x @ x.transpose(-1, -2)).sum()
-        want = seg.segment_device(x)
-        assert got.dtype == torch.int64 and tuple(got.shape) == (8, 64, 64)
-        assert torch.equal(got, want)
-        n += 1
+    torch.cuda.synchronize()
+    with (torch.cuda.stream(loader.compute_stream) if on_compute_stream else contextlib.nullcontext()):
+        for (x, y), (hi, hl) in zip(loader, batches):
+            ref_x = tf(torch.from_numpy(hi).to(DEV))
+            assert torch.equal(x, ref_x) and torch.equal(y.cpu(), torch.from_numpy(hl))
+            got = seg.segment(x)                                         # what the model's forward would receive
+            # (busy work on the consumer stream while the loader's next batch is being segmented on its own stream)
+            _ = (x @ x.transpose(-1, -2)).sum()
+            want = seg.segment_device(x)
+            assert got.dtype == torch.int64 and tuple(got.shape) == (8, 64, 64)
+            assert torch.equal(got, want)
+            n += 1
+    torch.cuda.synchronize()
     assert n == 4
     seg.set_label_maps(None)
 

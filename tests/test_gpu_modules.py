@@ -139,6 +139,46 @@ def test_sppp_model_logits(favit, nm):
     assert m.patch_embed.projection[1].weight.grad.abs().sum().item() > 0
 
 
+def test_token_bucketed_runs_batches_with_different_token_counts(favit):
+    """models.sppp.TokenBucketed: a batch whose images segment into 4 and 3 superpixel tokens (S and S - 1 for
+    num_superpixels = 4: the two counts the reference's positional encoding accepts, models/sppp.py:299).  The plain
+    model raises where the reference fails in torch.stack (models/sppp_mhla.py:300); the wrapper's logits per image, and
+    the parameter gradients of the batch's mean cross-entropy, equal those of the images run ONE BY ONE through the
+    wrapped model (a batch of one always stacks: what the reference computes per image)."""
+    torch.manual_seed(21)
+    S = 64
+    m = favit.models.sppp_mhla.SPPPViTMHLA(img_size=S, patch_size=8, num_classes=10, embed_dim=64, depth=2, num_heads=4,
+                                          num_superpixels=4, pooling_type="mean", window_size=3, use_mhla=True).to(DEV).train()
+    quad = (torch.arange(S)[:, None] >= S // 2).long() * 2 + (torch.arange(S)[None, :] >= S // 2).long()
+    tri = torch.where(quad == 1, torch.zeros_like(quad), quad)                     # top half one region: labels 0, 2, 3
+    maps = torch.stack([quad, tri, quad, tri, tri, quad]).contiguous().to(DEV)
+    x = torch.randn(6, 3, S, S, device=DEV)
+    y = torch.tensor([1, 4, 0, 9, 3, 3], device=DEV)
+    m.segmentation.set_label_maps(maps)
+    with pytest.raises(ValueError, match="different superpixel-token counts"):
+        m(x)
+    wrapped = favit.models.sppp.TokenBucketed(m)
+    logits = wrapped(x)
+    assert m.segmentation._maps is maps and m.assume_num_tokens is None          # restored
+    favit.train.cross_entropy(logits, y).backward()
+    got = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    for p in m.parameters():
+        p.grad = None
+    rows = []
+    for i in range(6):
+        m.segmentation.set_label_maps(maps[i:i + 1].contiguous())
+        li = m(x[i:i + 1])
+        rows.append(li.detach())
+        (favit.train.cross_entropy(li, y[i:i + 1]) / 6).backward()
+    assert rel_l2(logits.detach(), torch.cat(rows)) < 1e-5
+    for k, p in m.named_parameters():
+        assert p.grad is not None and rel_l2(got[k], p.grad) < 2e-4, k
+    # a batch with one count goes through in one piece
+    m.segmentation.set_label_maps(maps[[0, 2, 5]].contiguous())
+    assert rel_l2(wrapped(x[[0, 2, 5]]).detach(), torch.cat([rows[0], rows[2], rows[5]])) < 1e-5
+    m.segmentation.set_label_maps(None)
+
+
 def test_sppp_reference_dict_api(favit):
     c = case(SP, "vor16")
     seg = torch.from_numpy(c["segmap"].astype(np.int64)).to(DEV)

@@ -52,6 +52,11 @@ def main():
     ap.add_argument("--weight_decay", type=float, default=0.05)
     ap.add_argument("--head_learning_rate", type=float, default=1e-3)
     ap.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32", "fp8"])
+    ap.add_argument("--bucket_tokens", action="store_true",
+                    help="sppp_mhla: run batches that mix images with num_superpixels and num_superpixels - 1 tokens group by "
+                         "group (models.sppp.TokenBucketed; the reference -- and this tool without the flag -- fails on "
+                         "such a batch in torch.stack, models/sppp_mhla.py:300; any other count fails in the "
+                         "positional encoding, there and here)")
     a = ap.parse_args()
 
     pkg = importlib.import_module("focused-attention-vit_amd")
@@ -90,10 +95,18 @@ def main():
             return len(self.x) // a.batch_size
         def __iter__(self):
             return iter(batches(self.x, self.y, a.batch_size, self.shuffle, rs))
-    train_loader = pkg.data.DeviceLoader(Epochs(xtr, ytr, True), tfs["train"])
-    test_loader = pkg.data.DeviceLoader(Epochs(xte, yte, False), tfs["test"])
-    res = pkg.harness.fit(model, train_loader, test_loader, opt, a.epochs)
-    ev = pkg.harness.evaluate(model, test_loader, a.batch_size)
+    # SPPP: the loaders segment batch k + 1 (device SLIC on a CU-masked stream) under the step of batch k; the steps
+    # then run on the loader's compute stream, because a CU-masked stream synchronises with the default stream
+    seg = getattr(model, "segmentation", None)
+    train_loader = pkg.data.DeviceLoader(Epochs(xtr, ytr, True), tfs["train"], segmenter=seg)
+    test_loader = pkg.data.DeviceLoader(Epochs(xte, yte, False), tfs["test"], segmenter=seg)
+    work = train_loader.compute_stream if seg is not None else torch.cuda.current_stream()
+    work.wait_stream(torch.cuda.current_stream())
+    run = pkg.models.sppp.TokenBucketed(model) if (a.bucket_tokens and seg is not None) else model
+    with torch.cuda.stream(work):
+        res = pkg.harness.fit(run, train_loader, test_loader, opt, a.epochs)
+        ev = pkg.harness.evaluate(run, test_loader, a.batch_size)
+    torch.cuda.current_stream().wait_stream(work)
     row = {"model": a.experiment, "img_size": a.img_size, "patch_size": a.patch_size, "embed_dim": a.embed_dim, "depth": a.depth,
            "num_heads": a.num_heads, "window_size": a.window_size, "total_parameters": sum(p.numel() for p in model.parameters()),
            "avg_epoch_time": res["avg_epoch_time"], "total_training_time": res["total_training_time"],
