@@ -710,20 +710,13 @@ __device__ __forceinline__ void store16_policy(void* ptr, uint4 v, int policy) {
 constexpr int WEPI_LD = 68;                         // padded fp32 row
 constexpr int WEPI_BYTES = 32 * WEPI_LD * 4;        // 8704 B per wave
 
-// rows [16*Q, 16*(Q+NI)) of the wave's 64x64 accumulator tile (NI = 1 or 2 groups of 16 rows)
-template <typename InT, typename OutT, int Q, int NI, int NJ = 4, int CB = 0>
-__device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4 (&acc)[4][NJ], OutT* C, long mbase,
-                                              long nbase, int lane, float* wl, bool first_split, float alpha) {
+// rows [16*Q, 16*(Q+NI)) of the wave's 64x64 accumulator tile (NI = 1 or 2 groups of 16 rows), already deposited in
+// the wave's LDS scratch wl[16 * NI][WEPI_LD]: bias / activation / dropout / residual, then whole row segments out
+template <typename InT, typename OutT, int Q, int NI>
+__device__ __forceinline__ void wave_epilogue_tail(const KParams& p, OutT* C, long mbase, long nbase, int lane, float* wl,
+                                                   bool first_split, float alpha) {
   const bool fast = p.c_vec && (nbase + 64 <= p.N);
   {
-#pragma unroll
-    for (int ii = 0; ii < NI; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#ifdef FAVIT_PROBE
-        if (!(p.dbg & 0x1000))                                       // dbg 0x1000: no accumulator writes to the LDS scratch
-#endif
-        *reinterpret_cast<f32x4*>(wl + (ii * 16 + (lane & 15)) * WEPI_LD + j * 16 + 4 * (lane >> 4)) = acc[Q + ii][CB * 4 + j];
     // (same wave wrote and reads: the compiler's lgkmcnt wait orders them; no barrier needed)
     bool done = false;
     if constexpr (sizeof(OutT) == 4) {
@@ -866,6 +859,21 @@ __device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4
     }
     }  // !done
   }
+}
+
+// accumulators of the 16x16x32 MFMA layout (acc[i][j]: rows 16 i + (lane & 15), columns 16 j + 4 (lane >> 4) + e)
+template <typename InT, typename OutT, int Q, int NI, int NJ = 4, int CB = 0>
+__device__ __forceinline__ void wave_epilogue_rows(const KParams& p, const f32x4 (&acc)[4][NJ], OutT* C, long mbase,
+                                              long nbase, int lane, float* wl, bool first_split, float alpha) {
+#pragma unroll
+  for (int ii = 0; ii < NI; ++ii)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#ifdef FAVIT_PROBE
+      if (!(p.dbg & 0x1000))                                       // dbg 0x1000: no accumulator writes to the LDS scratch
+#endif
+      *reinterpret_cast<f32x4*>(wl + (ii * 16 + (lane & 15)) * WEPI_LD + j * 16 + 4 * (lane >> 4)) = acc[Q + ii][CB * 4 + j];
+  wave_epilogue_tail<InT, OutT, Q, NI>(p, C, mbase, nbase, lane, wl, first_split, alpha);
 }
 
 template <typename InT, typename OutT>
@@ -2305,8 +2313,8 @@ __global__ __launch_bounds__(256) void grouped_reduce_kernel(ReduceParams rp) {
 }
 
 template <typename Kn>
-int launch_p4(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st) {
-  g_last_kernel = "p4";
+int launch_p4(Kn kernel, const KParams& kp, dim3 grid, hipStream_t st, const char* name = "p4") {
+  g_last_kernel = name;
 #ifdef FAVIT_PROBE
   // FAVIT_GEMM_P4_ONE_PER_CU: claim 100 KiB of LDS so that only one workgroup fits a CU (occupancy experiment)
   static const int lds_bytes = getenv("FAVIT_GEMM_P4_ONE_PER_CU") ? 100 * 1024 : P4_LDS;
@@ -2486,6 +2494,177 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(KParams p) {
   }
 }
 
+// --------------------------------------------------------------------------------------
+// f32 kernel "p4f" (round 4): the p4 structure for exact fp32 -- 256x128 tile, 8 waves (64x64 each, four
+// v_mfma_f32_32x32x2_f32 accumulator blocks), BK = 16 (the same 64-byte stage rows, the same 24-KiB stages filled by
+// global_load_lds with counted vmcnt, one raw s_barrier per stage, two workgroups per CU), the wave-private epilogue.
+// The fp32 MFMA runs at 1/16 of the bf16 rate, so this kernel is MFMA-bound by construction: a stage is 32 MFMAs of 64
+// cycles per wave against 24 KiB of DMA, and a wave reads 4 KiB of fragments per 1,024 MFMA cycles.  It replaces the
+// register-staged 128x128 kernel of round 1 (__syncthreads per stage, scalar LDS writes: 0.30-0.41 of the 157 TF peak)
+// for the large GEMMs of the fp32 parity mode.
+//   k-major image : p4's ([rows][16 k], 64-B rows, 16-B chunk c at c ^ ksw32(row)); a lane reads ONE 16-byte chunk per
+//                   block row and 8-deep k group: lanes 0-31 chunk 2t, lanes 32-63 chunk 2t+1, i.e. the MFMA's two
+//                   k-slots are k = 8t + s and 8t + 4 + s in step s (A and B permute k identically);
+//   mn-major image: [16 k][W] floats (W = 256 / 128), k-rows whose bit 2 is set rotated by 32 words so that the two
+//                   lane halves of a fragment read (k-rows 8t + s and 8t + 4 + s) hit different banks.
+// --------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ const char* glds_src_f32_mn(const char* base, long ld, long i0, long I, long k0, int q, int lane) {
+  constexpr int LPR = W / 4;                           // lanes (16-byte chunks) per k-row
+  const int krow = q * (64 / LPR) + lane / LPR;
+  const int pc = lane % LPR;
+  const int c = (pc - 8 * ((krow >> 2) & 1)) & (LPR - 1);
+  long i = i0 + c * 4;
+  const long imax = (I - 4) & ~3L;
+  i = i < imax ? i : imax;
+  return base + ((k0 + krow) * ld + i) * 4;
+}
+
+template <bool AK, bool BKM, int TBM>
+__device__ __forceinline__ void p4f_body(const KParams& p, int tile, int split) {
+  static_assert(TBM == 256 || TBM == 128, "256x128 tiles, or 128x128 ones where those balance better");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NI = TBM / 128;                       // 32-row accumulator blocks per wave (wave tile 32 NI x 64)
+  constexpr int WR = 32 * NI;                         // rows per wave
+  constexpr int A_BYTES = TBM * 64;
+  constexpr int STAGE = A_BYTES + P4_B_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const long m0 = (long)(tile / p.tiles_n) * TBM;
+  const long n0 = (long)(tile % p.tiles_n) * BN;
+  const char* A = reinterpret_cast<const char*>(p.A);
+  const char* Bm = reinterpret_cast<const char*>(p.B);
+  float* C = reinterpret_cast<float*>(p.C);
+  const long kbeg = (long)split * p.k_per_split;
+  const long kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (int)((kend - kbeg) / BK32);
+
+  f32x16 acc[NI][2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0) && (wc == 0);
+  float rs[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) rs[i] = 0.f;
+
+  // DMA pieces of 1 KiB per wave and stage: NI of A (TBM / 16 pieces), 1 of B (8 pieces)
+  const char* sa[NI];
+  const char* sb;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int qa = wave * NI + j;
+    if (AK) sa[j] = reinterpret_cast<const char*>(glds_src32<true>(reinterpret_cast<const bf16_t*>(A), 2 * p.lda, m0, p.M, 2 * kbeg, qa, lane));
+    else sa[j] = glds_src_f32_mn<TBM>(A, p.lda, m0, p.M, kbeg, qa, lane);
+  }
+  if (BKM) sb = reinterpret_cast<const char*>(glds_src32<true>(reinterpret_cast<const bf16_t*>(Bm), 2 * p.ldb, n0, p.N, 2 * kbeg, wave, lane));
+  else sb = glds_src_f32_mn<128>(Bm, p.ldb, n0, p.N, kbeg, wave, lane);
+  const long a_step = AK ? 64 : (long)BK32 * p.lda * 4;      // bytes per stage
+  const long b_step = BKM ? 64 : (long)BK32 * p.ldb * 4;
+  auto issue = [&](int buf) {
+    char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + (wave * NI + j) * 1024), 16, 0, 0);
+      sa[j] += a_step;
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + A_BYTES + wave * 1024), 16, 0, 0);
+    sb += b_step;
+  };
+
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      if (NI == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);
+    const char* la = smem + cur * STAGE;
+    const char* lb = la + A_BYTES;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 a[NI], b[2];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (AK) {
+          const int row = wr * WR + i * 32 + l31;
+          a[i] = *reinterpret_cast<const f32x4*>(la + row * 64 + (((2 * t + h) ^ ksw32(row)) << 4));
+        } else {
+          const float* f = reinterpret_cast<const float*>(la) + (8 * t + 4 * h) * TBM + ((wr * WR + i * 32 + l31 + 32 * h) & (TBM - 1));
+          a[i] = (f32x4){f[0], f[TBM], f[2 * TBM], f[3 * TBM]};
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (BKM) {
+          const int row = wc * 64 + j * 32 + l31;
+          b[j] = *reinterpret_cast<const f32x4*>(lb + row * 64 + (((2 * t + h) ^ ksw32(row)) << 4));
+        } else {
+          const float* f = reinterpret_cast<const float*>(lb) + (8 * t + 4 * h) * 128 + ((wc * 64 + j * 32 + l31 + 32 * h) & 127);
+          b[j] = (f32x4){f[0], f[128], f[256], f[384]};
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0][s], a[i][s], acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[1][s], a[i][s], acc[i][1], 0, 0, 0);
+        }
+      if (do_rowsum) {                              // (wave-uniform) bias gradient: the column sums of the mn-major A
+#pragma unroll
+        for (int i = 0; i < NI; ++i) rs[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
+      }
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  if (do_rowsum) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float tot = rs[i] + __shfl_xor(rs[i], 32);
+      const long m = m0 + wr * WR + i * 32 + l31;
+      if (h == 0 && m < p.M) {
+        if (p.rowsum_store) p.a_rowsum[m] = tot;
+        else atomicAdd(p.a_rowsum + m, tot);
+      }
+    }
+  }
+  __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
+  float* wl = reinterpret_cast<float*>(smem + wave * WEPI_BYTES);
+  // deposit a block row (32 rows x 64 columns): a lane holds row (lane & 31), columns 32 j + 8 rg + 4 (lane >> 5) + e
+  auto deposit = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const f32x4 v0 = {c0[4 * rg], c0[4 * rg + 1], c0[4 * rg + 2], c0[4 * rg + 3]};
+      const f32x4 v1 = {c1[4 * rg], c1[4 * rg + 1], c1[4 * rg + 2], c1[4 * rg + 3]};
+      *reinterpret_cast<f32x4*>(wl + l31 * WEPI_LD + 8 * rg + 4 * h) = v0;
+      *reinterpret_cast<f32x4*>(wl + l31 * WEPI_LD + 32 + 8 * rg + 4 * h) = v1;
+    }
+  };
+  deposit(acc[0][0], acc[0][1]);
+  wave_epilogue_tail<float, float, 0, 2>(p, C, m0 + wr * WR, n0 + wc * 64, lane, wl, split == 0, p.alpha);
+  if constexpr (NI == 2) {
+    deposit(acc[1][0], acc[1][1]);
+    wave_epilogue_tail<float, float, 2, 2>(p, C, m0 + wr * WR, n0 + wc * 64, lane, wl, split == 0, p.alpha);
+  }
+}
+
+template <bool AK, bool BKM, int TBM>
+__global__ __launch_bounds__(P4_THREADS, 4) void gemm_f32_p4_kernel(KParams p) {
+  int tile, split;
+  tile_and_split(p, tile, split);
+  p4f_body<AK, BKM, TBM>(p, tile, split);
+}
+
 __global__ void zero_c_kernel(float* C, long M, long N, long ldc, long sCo, long sCi, int batch_inner) {
   const long z = blockIdx.z;
   float* c = C + (z / batch_inner) * sCo + (z % batch_inner) * sCi;
@@ -2509,7 +2688,7 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 // same result; the work-skipping probe switch (FAVIT_GEMM_DBG) exists only in the `make probe` build.
 struct GemmKnobs {
   int dbg, store_policy;
-  bool force128, no_p4, no_p7, no_s64, no_s64k2, no_pp, no_quarter;
+  bool force128, no_p4, no_p7, no_s64, no_s64k2, no_pp, no_quarter, no_f32p4;
   long quarter_max;
   GemmKnobs() {
     const char* e;
@@ -2524,6 +2703,7 @@ struct GemmKnobs {
     no_p7 = getenv("FAVIT_GEMM_NO_P7") != nullptr;
     no_s64 = getenv("FAVIT_GEMM_NO_S64") != nullptr;
     no_s64k2 = getenv("FAVIT_GEMM_NO_S64K2") != nullptr;
+    no_f32p4 = getenv("FAVIT_GEMM_NO_F32P4") != nullptr;
     no_pp = getenv("FAVIT_GEMM_NO_PP") != nullptr;
     no_quarter = getenv("FAVIT_GEMM_NO_QUARTER") != nullptr;
     quarter_max = (e = getenv("FAVIT_GEMM_QUARTER_MAX")) ? atol(e) : 128;       // tail rounds up to 25 % of the slots
@@ -2584,6 +2764,33 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
       const long max_splits = g->K / (4 * bk);
       if (splits > max_splits) splits = max_splits;
       if (splits < 1) splits = 1;
+    }
+  }
+  // exact-fp32 problems the DMA kernel takes (p4f; alignment is checked at the dispatch below).  It is MFMA-bound, so
+  // what counts is how evenly the work falls on the 256 CUs and how many rows of the last tile row are padding:
+  // 256- or 128-row tiles by that measure, and a weight gradient is split into as many k-ranges as fill 512 slots.
+  const bool f32p4_shape = g->in_dtype == FAVIT_F32 && !fp8 && batch == 1 && !knobs().no_f32p4 && (g->K % BK32) == 0 &&
+                           g->K >= 4 * BK32 && (g->a_kmajor || (g->M >= 4 && (g->M % 4) == 0)) &&
+                           (g->b_kmajor || (g->N >= 4 && (g->N % 4) == 0));
+  int f32_tbm = 256;
+  long t4f = ((g->M + 255) / 256) * tiles_n;
+  if (f32p4_shape) {
+    const bool auto_split = g->split_k <= 0 && splits > 1;
+    double best = -1.0;
+    for (int tbm = 256; tbm >= 128; tbm -= 128) {
+      const long tm = (g->M + tbm - 1) / tbm, t = tm * tiles_n;
+      long sp = splits;
+      if (auto_split) {
+        sp = (512 + t / 2) / t;                                               // 72 KiB of LDS either way: 2 workgroups per CU
+        const long max_splits = g->K / (4 * 64);
+        sp = sp > max_splits ? max_splits : sp;
+        sp = sp < 1 ? 1 : sp;
+      }
+      const double per_cu = (double)t * sp / 256.0;                           // tiles per CU: the busiest CU takes the ceiling
+      const double balance = per_cu / (double)(long)(per_cu + 0.999999);
+      const double useful = (double)g->M / (double)(tm * tbm);
+      const double score = balance * useful * (tbm == 256 ? 1.02 : 1.0);      // (tie: the larger tile)
+      if (score > best) { best = score; f32_tbm = tbm; t4f = t; if (auto_split) splits = sp; }
     }
   }
   if (splits > 1 && !can_split) return FAVIT_ERR_UNSUPPORTED;
@@ -2818,6 +3025,27 @@ extern "C" int favit_gemm(const favit_gemm_t* g, void* stream) {
         case 1: return launch(gemm_bf16_glds_kernel<false, true, float>, kp, grid, st);
         default: return launch(gemm_bf16_glds_kernel<false, false, float>, kp, grid, st);
       }
+    }
+  }
+  // exact fp32, large problems: the 256x128 DMA kernel (p4f).  Small ones keep the 128x128 tiles below: with fewer
+  // than one 256x128 workgroup per CU the finer tiles balance better and the launch is latency-bound anyway.
+  if (f32p4_shape && kp.a_vec && kp.b_vec && (kps % BK32) == 0 && t4f * splits * (f32_tbm / 128) >= 384) {
+    KParams kf = kp;
+    kf.ntiles = (int)t4f;
+    const dim3 gridf((unsigned)t4f, (unsigned)splits, 1u);
+    if (f32_tbm == 256) {
+      switch (layout) {
+        case 3: return launch_p4(gemm_f32_p4_kernel<true, true, 256>, kf, gridf, st, "p4f");
+        case 2: return launch_p4(gemm_f32_p4_kernel<true, false, 256>, kf, gridf, st, "p4f");
+        case 1: return launch_p4(gemm_f32_p4_kernel<false, true, 256>, kf, gridf, st, "p4f");
+        default: return launch_p4(gemm_f32_p4_kernel<false, false, 256>, kf, gridf, st, "p4f");
+      }
+    }
+    switch (layout) {
+      case 3: return launch_p4(gemm_f32_p4_kernel<true, true, 128>, kf, gridf, st, "p4f128");
+      case 2: return launch_p4(gemm_f32_p4_kernel<true, false, 128>, kf, gridf, st, "p4f128");
+      case 1: return launch_p4(gemm_f32_p4_kernel<false, true, 128>, kf, gridf, st, "p4f128");
+      default: return launch_p4(gemm_f32_p4_kernel<false, false, 128>, kf, gridf, st, "p4f128");
     }
   }
   if (g->in_dtype == FAVIT_BF16) {

@@ -806,6 +806,63 @@ def _abi():
     return importlib.import_module("focused-attention-vit_amd")._abi
 
 
+@pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,Kd", [(50432, 384, 384), (8192 + 40, 1152, 400), (32768 + 4, 200, 64), (36928, 768, 768)])
+@pytest.mark.parametrize("epi", ["plain", "gelu", "dgelu", "res"])
+def test_gemm_exact_fp32_dma_kernel(K, favit, ak, bk, M, N, Kd, epi):
+    """The exact-fp32 256x128 DMA kernel (p4f: global_load_lds ring + v_mfma_f32_32x32x2_f32; the GEMMs of the fp32
+    parity mode at benchmark sizes): every operand layout, ragged M and N tiles, fused epilogues, against an fp64
+    product."""
+    g = torch.Generator(device=DEV).manual_seed(91)
+    a = _rand((M, Kd) if ak else (Kd, M), torch.float32, g)
+    b = _rand((N, Kd) if bk else (Kd, N), torch.float32, g)
+    bias = _rand((N,), torch.float32, g)
+    out = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ref = ((a if ak else a.t()).double() @ (b.t() if bk else b).double())
+    lda, ldb = (Kd if ak else M), (Kd if bk else N)
+    kw = dict(a_kmajor=ak, b_kmajor=bk)
+    A = _abi()
+    if epi == "plain":
+        K.gemm(a, b, out, M, N, Kd, lda, ldb, N, **kw)
+    elif epi == "gelu":
+        pre = torch.empty_like(out)
+        K.gemm(a, b, out, M, N, Kd, lda, ldb, N, bias=bias, act=A.ACT_GELU, aux_out=pre, ld_aux_out=N, **kw)
+        ref = ref + bias.double()
+        assert rel_l2(pre.double(), ref) < 2e-6
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == "dgelu":
+        pre = _rand((M, N), torch.float32, g)
+        K.gemm(a, b, out, M, N, Kd, lda, ldb, N, act=A.ACT_DGELU, aux_in=pre, ld_aux_in=N, **kw)
+        x = pre.double().requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        ref = ref * x.grad
+    else:
+        res = _rand((M, N), torch.float32, g)
+        K.gemm(a, b, out, M, N, Kd, lda, ldb, N, bias=bias, residual=res, ld_res=N, alpha=0.5, **kw)
+        ref = 0.5 * ref + bias.double() + res.double()
+    assert favit._abi.lib().favit_gemm_last_kernel().decode() in ("p4f", "p4f128")     # (256- or 128-row tiles: by balance)
+    assert rel_l2(out.double(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,T", [(1536, 384, 50432), (384, 1536, 50432), (1152, 384, 50432), (768, 3072, 36928), (200, 136, 65536)])
+def test_gemm_exact_fp32_dma_kernel_weight_gradients(K, favit, M, N, T):
+    """The same kernel on the weight-gradient shape (both operands token-major, split over the tokens with fp32 atomics,
+    fused bias gradient), from zero and accumulating into an existing gradient."""
+    g = torch.Generator(device=DEV).manual_seed(92)
+    dy = _rand((T, M), torch.float32, g)
+    x = _rand((T, N), torch.float32, g)
+    dw = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    db = torch.zeros((M,), dtype=torch.float32, device=DEV)
+    K.gemm(dy, x, dw, M, N, T, M, N, N, a_kmajor=False, b_kmajor=False, a_rowsum=db)
+    assert favit._abi.lib().favit_gemm_last_kernel().decode() in ("p4f", "p4f128")
+    ref = dy.double().t() @ x.double()
+    assert rel_l2(dw.double(), ref) < 2e-6
+    assert rel_l2(db.double(), dy.double().sum(0)) < 2e-6
+    K.gemm(dy, x, dw, M, N, T, M, N, N, a_kmajor=False, b_kmajor=False, a_rowsum=db, accumulate=True)
+    assert rel_l2(dw.double(), 2 * ref) < 2e-6
+    assert rel_l2(db.double(), 2 * dy.double().sum(0)) < 2e-6
+
+
 @pytest.mark.parametrize("bk", [True, False])
 @pytest.mark.parametrize("out_dtype,epi", [(torch.bfloat16, "gelu"), (torch.bfloat16, "dgelu"), (torch.float32, "res")])
 def test_gemm_256x256_tile_kernel(K, bk, out_dtype, epi):

@@ -28,7 +28,7 @@ def run(name, fn, flops):
     us = e0.elapsed_time(e1) * 1e3 / reps
     print(f"{name:28s} {us:9.1f} us  {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
 
-bf = torch.bfloat16
+bf = torch.float32 if os.environ.get("F32") else torch.bfloat16        # F32=1: the exact-fp32 kernels on the same shapes
 def rnd(*s, dt=bf): return torch.randn(*s, device=dev).to(dt)
 x = rnd(T, D); h = rnd(T, 4 * D)
 wqkv = rnd(3 * D, D); w1 = rnd(4 * D, D); w2 = rnd(D, 4 * D); wp = rnd(D, D)
