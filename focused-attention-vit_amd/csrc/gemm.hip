@@ -2520,12 +2520,18 @@ __device__ __forceinline__ const char* glds_src_f32_mn(const char* base, long ld
   return base + ((k0 + krow) * ld + i) * 4;
 }
 
-template <bool AK, bool BKM, int TBM>
+template <bool AK, bool BKM, int TBM, int NW>
 __device__ __forceinline__ void p4f_body(const KParams& p, int tile, int split) {
   static_assert(TBM == 256 || TBM == 128, "256x128 tiles, or 128x128 ones where those balance better");
+  // NW = 4 (2x2 waves of 128 / 64 rows, 174-182 VGPRs, two waves per SIMD from two workgroups) was measured: 8192^3
+  // 139.8 TF against 132.5 with eight waves, but every shape of the path slower (fc2 forward 587 us against 501, qkv 531
+  // against 445: four waves take twice as long over the epilogue); the bare MFMA loop (tools/mfma_peak.py) holds
+  // 153.6 TF with one or two waves per SIMD and 120 TF with four.
+  static_assert(NW == 8 || NW == 4, "eight waves as 4x2, or four as 2x2 with twice the rows per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NI = TBM / 128;                       // 32-row accumulator blocks per wave (wave tile 32 NI x 64)
-  constexpr int WR = 32 * NI;                         // rows per wave
+  constexpr int WR = TBM / (NW / 2);                  // rows per wave (the wave tile is WR x 64)
+  constexpr int NI = WR / 32;                         // 32-row accumulator blocks per wave
+  constexpr int PA = TBM / 16 / NW, PB = 8 / NW;      // 1-KiB DMA pieces per wave and stage
   constexpr int A_BYTES = TBM * 64;
   constexpr int STAGE = A_BYTES + P4_B_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2554,36 +2560,44 @@ __device__ __forceinline__ void p4f_body(const KParams& p, int tile, int split) 
 #pragma unroll
   for (int i = 0; i < NI; ++i) rs[i] = 0.f;
 
-  // DMA pieces of 1 KiB per wave and stage: NI of A (TBM / 16 pieces), 1 of B (8 pieces)
-  const char* sa[NI];
-  const char* sb;
+  const char* sa[PA];
+  const char* sb[PB];
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int qa = wave * NI + j;
+  for (int j = 0; j < PA; ++j) {
+    const int qa = wave * PA + j;
     if (AK) sa[j] = reinterpret_cast<const char*>(glds_src32<true>(reinterpret_cast<const bf16_t*>(A), 2 * p.lda, m0, p.M, 2 * kbeg, qa, lane));
     else sa[j] = glds_src_f32_mn<TBM>(A, p.lda, m0, p.M, kbeg, qa, lane);
   }
-  if (BKM) sb = reinterpret_cast<const char*>(glds_src32<true>(reinterpret_cast<const bf16_t*>(Bm), 2 * p.ldb, n0, p.N, 2 * kbeg, wave, lane));
-  else sb = glds_src_f32_mn<128>(Bm, p.ldb, n0, p.N, kbeg, wave, lane);
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int qb = wave * PB + j;
+    if (BKM) sb[j] = reinterpret_cast<const char*>(glds_src32<true>(reinterpret_cast<const bf16_t*>(Bm), 2 * p.ldb, n0, p.N, 2 * kbeg, qb, lane));
+    else sb[j] = glds_src_f32_mn<128>(Bm, p.ldb, n0, p.N, kbeg, qb, lane);
+  }
   const long a_step = AK ? 64 : (long)BK32 * p.lda * 4;      // bytes per stage
   const long b_step = BKM ? 64 : (long)BK32 * p.ldb * 4;
   auto issue = [&](int buf) {
     char* st = smem + buf * STAGE;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + (wave * NI + j) * 1024), 16, 0, 0);
+    for (int j = 0; j < PA; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + (wave * PA + j) * 1024), 16, 0, 0);
       sa[j] += a_step;
     }
-    __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + A_BYTES + wave * 1024), 16, 0, 0);
-    sb += b_step;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sb[j], (lptr_t)(st + A_BYTES + (wave * PB + j) * 1024), 16, 0, 0);
+      sb[j] += b_step;
+    }
   };
 
   if (nk > 0) issue(0);
   if (nk > 1) issue(1);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      if (NI == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (kt + 1 < nk) {                                  // the newest stage (PA + PB pieces of this wave) may still fly
+      if constexpr (PA + PB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (PA + PB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (PA + PB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -2613,6 +2627,7 @@ __device__ __forceinline__ void p4f_body(const KParams& p, int tile, int split) 
           b[j] = (f32x4){f[0], f[128], f[256], f[384]};
         }
       }
+      // (s_setprio 1 around the 8 NI MFMAs of a group, so that the arbiter stays with one wave: 8192^3 132.5 -> 108.6 TF)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -2650,11 +2665,18 @@ __device__ __forceinline__ void p4f_body(const KParams& p, int tile, int split) 
       *reinterpret_cast<f32x4*>(wl + l31 * WEPI_LD + 32 + 8 * rg + 4 * h) = v1;
     }
   };
+  const long mb = m0 + wr * WR, nb = n0 + wc * 64;
   deposit(acc[0][0], acc[0][1]);
-  wave_epilogue_tail<float, float, 0, 2>(p, C, m0 + wr * WR, n0 + wc * 64, lane, wl, split == 0, p.alpha);
-  if constexpr (NI == 2) {
+  wave_epilogue_tail<float, float, 0, 2>(p, C, mb, nb, lane, wl, split == 0, p.alpha);
+  if constexpr (NI >= 2) {
     deposit(acc[1][0], acc[1][1]);
-    wave_epilogue_tail<float, float, 2, 2>(p, C, m0 + wr * WR, n0 + wc * 64, lane, wl, split == 0, p.alpha);
+    wave_epilogue_tail<float, float, 2, 2>(p, C, mb, nb, lane, wl, split == 0, p.alpha);
+  }
+  if constexpr (NI == 4) {
+    deposit(acc[2][0], acc[2][1]);
+    wave_epilogue_tail<float, float, 4, 2>(p, C, mb, nb, lane, wl, split == 0, p.alpha);
+    deposit(acc[3][0], acc[3][1]);
+    wave_epilogue_tail<float, float, 6, 2>(p, C, mb, nb, lane, wl, split == 0, p.alpha);
   }
 }
 
@@ -2662,7 +2684,7 @@ template <bool AK, bool BKM, int TBM>
 __global__ __launch_bounds__(P4_THREADS, 4) void gemm_f32_p4_kernel(KParams p) {
   int tile, split;
   tile_and_split(p, tile, split);
-  p4f_body<AK, BKM, TBM>(p, tile, split);
+  p4f_body<AK, BKM, TBM, 8>(p, tile, split);
 }
 
 __global__ void zero_c_kernel(float* C, long M, long N, long ldc, long sCo, long sCi, int batch_inner) {

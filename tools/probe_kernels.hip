@@ -211,3 +211,42 @@ extern "C" int probe_mfma_peak(const void* seed, int iters, int blocks, void* ou
                      (unsigned long long*)out, (float*)sink);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---- the same for the exact-fp32 instruction of the parity mode: v_mfma_f32_32x32x2_f32, four 16-register accumulators ----
+typedef __attribute__((ext_vector_type(16))) float pf32x16;
+__global__ __launch_bounds__(256) void mfma_peak_f32_kernel(const float* __restrict__ seed, int iters, unsigned long long* out,
+                                                            float* sink) {
+  const int tid = threadIdx.x;
+  float a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = seed[(tid * 8 + i) & 4095]; b[i] = seed[(tid * 8 + 4 + i) & 4095]; }
+  pf32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[s], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[(s + 1) & 3], a[s], acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[(s + 1) & 3], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[(s + 2) & 3], a[s], acc[3], 0, 0, 0);
+    }
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += acc[i][r];
+  if (sum == 12345.678f) sink[0] = sum;
+  if (tid == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+extern "C" int probe_mfma_peak_f32(const void* seed, int iters, int blocks, void* out, void* sink, void* stream) {
+  hipLaunchKernelGGL(mfma_peak_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)seed, iters,
+                     (unsigned long long*)out, (float*)sink);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
