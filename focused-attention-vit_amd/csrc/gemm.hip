@@ -2,13 +2,16 @@
 //
 //   C[m,n] = epilogue( alpha * sum_k A[m,k] * B[n,k] )
 //
-// Three bf16 kernels share the fragment / epilogue code below:
+// The bf16 kernels share the fragment / epilogue code below:
 //   * "p4" (the hot one): 256x128 tile, 8 waves, BK = 32, three LDS stages filled by
 //     global_load_lds with a counted vmcnt, wave-private transpose epilogue, 2 workgroups per CU;
-//     also runs the grouped / XCD-affine split-K weight-gradient launch
+//     also runs the grouped weight-gradient launch (chunks / K-splits / per-XCD queues) and the fp8 operands
+//   * "p7" 256x256 (K >= 512, N % 256 == 0), "pp" ping-pong (K >= 4096), "s64" / "s64k2" 64-row tiles for
+//     launches with fewer tiles than CUs, "s64ln" (LayerNorm fused, off), "pd" (persistent, deferred epilogue: off)
 //   * "glds": 128x128 tile, direct-to-LDS double buffer (small and batched problems)
 //   * the register-staged 128x128 kernel (any shape / alignment; the fallback)
-// and one exact-fp32 kernel (the parity mode).  In the 128x128 kernels a 256-thread workgroup
+// and two exact-fp32 kernels (the parity mode): "p4f", the p4 structure with v_mfma_f32_32x32x2_f32 for the large
+// problems, and the register-staged 128x128 one.  In the 128x128 kernels a 256-thread workgroup
 // (4 waves, 2x2) owns the tile, each wave a 64x64 sub-tile; operands are consumed from LDS as
 // MFMA fragments:
 //   bf16 : v_mfma_f32_16x16x32_bf16, BK = 64.
@@ -17,7 +20,7 @@
 //          mn-major operand -> LDS image [k][128] (256-B rows), 32-B XOR swizzle,
 //                              fragment = two ds_read_b64_tr_b16 (hardware transpose)
 //   f32  : v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), BK = 16, LDS image [k][132]
-//          for both layouts, fragment = ds_read_b32.
+//          for both layouts, fragment = ds_read_b32 (p4f: see its own header).
 // The MFMA is issued with the B-side fragment as the "A" operand so that every lane ends
 // up with 4 consecutive n for one m: the accumulators go to LDS as float4 and the
 // epilogue (bias / GELU / dGELU / residual / atomics) runs on full coalesced rows.

@@ -30,15 +30,65 @@ __device__ __forceinline__ float4 load4(const InT* p) {
   }
 }
 
-template <typename OutT, int NV>
+// fp8 mode (round 4): the bf16 tensor a LayerNorm pass produces -- the normalised rows that feed the qkv / fc1 GEMMs,
+// the low-precision copy of the stream gradient that feeds the fc2 / proj input-gradient GEMMs -- leaves the pass
+// QUANTISED as well, with the consumer site's delayed scale, instead of being re-read by a stand-alone quantising pass
+// (favit_fp8_quantize: 18.9 us per 768-wide tensor at cfg4, 48 of them per step).  Same protocol and the same
+// arithmetic as that kernel (fp8.hip): the scale is FMAX / max(amax[0..255]) of the site's previous call, the values
+// are the ROUNDED bf16 ones, their maximum goes to amax_next (atomics spread over the slots), workgroup 0 writes
+// scale_inv and clears amax_clear -- so the bytes, the scale and the history are bit-identical to the two-pass form.
+struct LnQ8 {
+  uint8_t* q;                 // [rows, D] fp8 (NULL: off)
+  const float* amax;          // FAVIT_FP8_AMAX_SLOTS partial maxima measured by the previous call
+  float* scale_inv;
+  float* amax_next;
+  float* amax_clear;
+  int fmt;                    // FAVIT_E4M3 / FAVIT_E5M2
+};
+
+__device__ __forceinline__ float lnq8_begin(const LnQ8& q8, int lane) {
+  const float fmax = q8.fmt == FAVIT_E4M3 ? 448.0f : 57344.0f;
+  float am = 0.f;
+  for (int i = lane; i < FAVIT_FP8_AMAX_SLOTS; i += 64) am = fmaxf(am, q8.amax[i]);
+  am = wave_max(am);
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) q8.scale_inv[0] = am > 0.f ? __fdiv_rn(am, fmax) : 1.0f;
+    if (threadIdx.x < FAVIT_FP8_AMAX_SLOTS) q8.amax_clear[threadIdx.x] = 0.f;
+  }
+  return am > 0.f ? __fdiv_rn(fmax, am) : 1.0f;
+}
+// four values as the bf16 copy holds them -> four fp8 bytes; m tracks max |value|
+__device__ __forceinline__ unsigned lnq8_pack(float a, float b, float c, float d, float scale, int fmt, float& m) {
+  const float fmax = fmt == FAVIT_E4M3 ? 448.0f : 57344.0f;
+  a = (float)(bf16_t)a; b = (float)(bf16_t)b; c = (float)(bf16_t)c; d = (float)(bf16_t)d;
+  m = fmaxf(fmaxf(m, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
+  a = fminf(fmaxf(a * scale, -fmax), fmax); b = fminf(fmaxf(b * scale, -fmax), fmax);
+  c = fminf(fmaxf(c * scale, -fmax), fmax); d = fminf(fmaxf(d * scale, -fmax), fmax);
+  if (fmt == FAVIT_E4M3)
+    return ((unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu) |
+           ((unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, 0, false) << 16);
+  return ((unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xffffu) |
+         ((unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(c, d, 0, false) << 16);
+}
+__device__ __forceinline__ void lnq8_end(const LnQ8& q8, float m, int lane, int wave) {
+  m = wave_max(m);
+  if (lane == 0 && m > 0.f)
+    atomicMax(reinterpret_cast<unsigned int*>(q8.amax_next) + ((blockIdx.x * 4 + wave) & (FAVIT_FP8_AMAX_SLOTS - 1)),
+              __float_as_uint(m));
+}
+
+template <typename OutT, int NV, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, OutT* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long rows,
-                                                     int D, float eps) {
+                                                     int D, float eps, LnQ8 q8) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long row = (long)blockIdx.x * 4 + wave;
-  if (row >= rows) return;
+  float qscale = 1.0f, qmax = 0.f;
+  if constexpr (Q8) qscale = lnq8_begin(q8, lane);
+  // (one row per wave and launch without the quantisation; with it the grid is capped and a wave walks several rows,
+  // so that the scale's round trip and the amax atomic are paid once per wave: 56 -> see tools/lnq8_bench.py)
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
   const float* xr = x + row * ldx;
   const int nchunk = D >> 2;
   float4 v[NV];
@@ -71,10 +121,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (i4 < nchunk) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * i4);
       const float4 b = *reinterpret_cast<const float4*>(beta + 4 * i4);
-      store4<OutT>(yr + 4 * i4, (v[c].x - mu) * rs * g.x + b.x, (v[c].y - mu) * rs * g.y + b.y,
-                   (v[c].z - mu) * rs * g.z + b.z, (v[c].w - mu) * rs * g.w + b.w);
+      const float o0 = (v[c].x - mu) * rs * g.x + b.x, o1 = (v[c].y - mu) * rs * g.y + b.y;
+      const float o2 = (v[c].z - mu) * rs * g.z + b.z, o3 = (v[c].w - mu) * rs * g.w + b.w;
+      store4<OutT>(yr + 4 * i4, o0, o1, o2, o3);
+      if constexpr (Q8)
+        *reinterpret_cast<unsigned*>(q8.q + row * (long)D + 4 * i4) = lnq8_pack(o0, o1, o2, o3, qscale, q8.fmt, qmax);
     }
   }
+  }
+  if constexpr (Q8) lnq8_end(q8, qmax, lane, wave);
 }
 
 // sum over the 32 lanes of an aligned half wave, in the VALU (DPP within rows of 16, v_permlane16_swap across them)
@@ -87,14 +142,17 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 // Forward for D <= 512: TWO rows per wave, 32 lanes per row, NV float4 per lane.  At D = 384 every lane carries three
 // vectors (the one-row-per-wave kernel above leaves half of its second vector idle and has 1.5 KB in flight per wave),
 // and the two reductions cost five VALU exchanges each instead of six ds_bpermute round trips.
-template <typename OutT, int NV>
+template <typename OutT, int NV, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_half_kernel(const float* __restrict__ x, long ldx,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, OutT* __restrict__ y,
                                                           float* __restrict__ mean, float* __restrict__ rstd, long rows,
-                                                          int D, float eps) {
+                                                          int D, float eps, LnQ8 q8) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l32 = lane & 31;
-  const long row0 = ((long)blockIdx.x * 4 + wave) * 2 + (lane >> 5);
+  float qscale = 1.0f, qmax = 0.f;
+  if constexpr (Q8) qscale = lnq8_begin(q8, lane);
+  for (long pair = (long)blockIdx.x * 4 + wave; 2 * pair < rows; pair += (long)gridDim.x * 4) {
+  const long row0 = pair * 2 + (lane >> 5);
   const bool live = row0 < rows;
   const long row = live ? row0 : rows - 1;               // a dead half recomputes the last row and stores nothing
   const float* xr = x + row * ldx;
@@ -118,25 +176,31 @@ __global__ __launch_bounds__(256) void ln_fwd_half_kernel(const float* __restric
     }
   }
   const float rs = rsqrtf(half_wave_sum(q) / (float)D + eps);
-  if (!live) return;
-  if (l32 == 0) {
-    mean[row] = mu;
-    rstd[row] = rs;
-  }
-  OutT* yr = y + row * (long)D;
+  if (live) {
+    if (l32 == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+    OutT* yr = y + row * (long)D;
 #pragma unroll
-  for (int c = 0; c < NV; ++c) {
-    const int i4 = l32 + 32 * c;
-    if (i4 < nchunk) {
-      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * i4);
-      const float4 b = *reinterpret_cast<const float4*>(beta + 4 * i4);
-      store4<OutT>(yr + 4 * i4, (v[c].x - mu) * rs * g.x + b.x, (v[c].y - mu) * rs * g.y + b.y,
-                   (v[c].z - mu) * rs * g.z + b.z, (v[c].w - mu) * rs * g.w + b.w);
+    for (int c = 0; c < NV; ++c) {
+      const int i4 = l32 + 32 * c;
+      if (i4 < nchunk) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * i4);
+        const float4 b = *reinterpret_cast<const float4*>(beta + 4 * i4);
+        const float o0 = (v[c].x - mu) * rs * g.x + b.x, o1 = (v[c].y - mu) * rs * g.y + b.y;
+        const float o2 = (v[c].z - mu) * rs * g.z + b.z, o3 = (v[c].w - mu) * rs * g.w + b.w;
+        store4<OutT>(yr + 4 * i4, o0, o1, o2, o3);
+        if constexpr (Q8)
+          *reinterpret_cast<unsigned*>(q8.q + row * (long)D + 4 * i4) = lnq8_pack(o0, o1, o2, o3, qscale, q8.fmt, qmax);
+      }
     }
   }
+  }
+  if constexpr (Q8) lnq8_end(q8, qmax, lane, wave);
 }
 
-template <typename DyT, typename LpT, int NV>
+template <typename DyT, typename LpT, int NV, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -144,7 +208,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy,
                                                      long lddx, LpT* __restrict__ dx_lp,
                                                      float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
                                                      long rows, int D, uint32_t lp_thresh, float lp_scale,
-                                                     uint64_t lp_seed, const unsigned long long* lp_epoch) {
+                                                     uint64_t lp_seed, const unsigned long long* lp_epoch, LnQ8 q8) {
+  float qscale = 1.0f, qmax = 0.f;
+  if constexpr (Q8) qscale = lnq8_begin(q8, threadIdx.x & 63);
   if (lp_thresh) lp_seed = favit_eff_seed(lp_seed, lp_epoch);
   __shared__ float red[4][2][256 * NV > 2048 ? 2048 : 256 * NV];   // [wave][gamma|beta][D padded]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -202,10 +268,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy,
             o3 = favit_keep(lp_seed, e + 3, lp_thresh) ? o3 * lp_scale : 0.f;
           }
           store4<LpT>(dx_lp + row * (long)D + 4 * i4, o0, o1, o2, o3);
+          if constexpr (Q8)
+            *reinterpret_cast<unsigned*>(q8.q + row * (long)D + 4 * i4) = lnq8_pack(o0, o1, o2, o3, qscale, q8.fmt, qmax);
         }
       }
     }
   }
+  if constexpr (Q8) lnq8_end(q8, qmax, lane, wave);
   // fold the 4 waves of the workgroup, then one partial row per workgroup
 #pragma unroll
   for (int c = 0; c < NV; ++c) {
@@ -571,22 +640,26 @@ inline int grid_for(long n, int block = 256, int cap = 4096) {
     else return FAVIT_ERR_UNSUPPORTED;      \
   } while (0)
 
-extern "C" int favit_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y,
-                                   int y_dtype, float* mean, float* rstd, int64_t rows, int32_t D, float eps,
-                                   void* stream) {
+namespace {
+int layernorm_fwd_impl(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, int y_dtype, float* mean,
+                       float* rstd, int64_t rows, int32_t D, float eps, const LnQ8& q8, void* stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || D <= 0) return FAVIT_ERR_INVALID;
   if ((D & 3) || (ldx & 3)) return FAVIT_ERR_ALIGN;
   hipStream_t st = as_stream(stream);
   if (D <= 512 && getenv("FAVIT_LN_ONE_ROW") == nullptr) {          // two rows per wave
-    const dim3 grid2((unsigned)((rows + 7) / 8));
+    const long nb2 = (rows + 7) / 8;
+    const dim3 grid2((unsigned)(q8.q && nb2 > 2048 ? 2048 : nb2));
 #define LN_FWD2(NV)                                                                                                 \
     do {                                                                                                            \
-      if (y_dtype == FAVIT_F32)                                                                                     \
+      if (q8.q)                                                                                                     \
+        hipLaunchKernelGGL((ln_fwd_half_kernel<bf16_t, NV, true>), grid2, dim3(256), 0, st, x, (long)ldx, gamma,    \
+                           beta, (bf16_t*)y, mean, rstd, (long)rows, D, eps, q8);                                   \
+      else if (y_dtype == FAVIT_F32)                                                                                \
         hipLaunchKernelGGL((ln_fwd_half_kernel<float, NV>), grid2, dim3(256), 0, st, x, (long)ldx, gamma, beta,     \
-                           (float*)y, mean, rstd, (long)rows, D, eps);                                              \
+                           (float*)y, mean, rstd, (long)rows, D, eps, q8);                                          \
       else                                                                                                          \
         hipLaunchKernelGGL((ln_fwd_half_kernel<bf16_t, NV>), grid2, dim3(256), 0, st, x, (long)ldx, gamma, beta,    \
-                           (bf16_t*)y, mean, rstd, (long)rows, D, eps);                                             \
+                           (bf16_t*)y, mean, rstd, (long)rows, D, eps, q8);                                         \
     } while (0)
     const int nv2 = (D + 127) / 128;
     if (nv2 <= 1) LN_FWD2(1); else if (nv2 == 2) LN_FWD2(2); else if (nv2 == 3) LN_FWD2(3); else LN_FWD2(4);
@@ -594,25 +667,29 @@ extern "C" int favit_layernorm_fwd(const float* x, int64_t ldx, const float* gam
     FAVIT_CHECK_LAUNCH();
     return FAVIT_OK;
   }
-  const dim3 grid((unsigned)((rows + 3) / 4));
+  const long nb1 = (rows + 3) / 4;
+  const dim3 grid((unsigned)(q8.q && nb1 > 2048 ? 2048 : nb1));
 #define LN_FWD(NV)                                                                                              \
-  if (y_dtype == FAVIT_F32)                                                                                     \
+  if (q8.q)                                                                                                     \
+    hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NV, true>), grid, dim3(256), 0, st, x, (long)ldx, gamma, beta,    \
+                       (bf16_t*)y, mean, rstd, (long)rows, D, eps, q8);                                         \
+  else if (y_dtype == FAVIT_F32)                                                                                \
     hipLaunchKernelGGL((ln_fwd_kernel<float, NV>), grid, dim3(256), 0, st, x, (long)ldx, gamma, beta, (float*)y, \
-                       mean, rstd, (long)rows, D, eps);                                                         \
+                       mean, rstd, (long)rows, D, eps, q8);                                                     \
   else                                                                                                          \
     hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, NV>), grid, dim3(256), 0, st, x, (long)ldx, gamma, beta,          \
-                       (bf16_t*)y, mean, rstd, (long)rows, D, eps)
+                       (bf16_t*)y, mean, rstd, (long)rows, D, eps, q8)
   LN_DISPATCH_NV(D, LN_FWD);
 #undef LN_FWD
   FAVIT_CHECK_LAUNCH();
   return FAVIT_OK;
 }
 
-extern "C" int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x, int64_t ldx, const float* gamma,
-                                   const float* mean, const float* rstd, const float* dres, float* dx, int64_t lddx,
-                                   void* dx_lp, int lp_dtype, float* dgamma_part, float* dbeta_part, int32_t nparts,
-                                   float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t D,
-                                   float lp_dropout_p, uint64_t lp_dropout_seed, void* stream) {
+int layernorm_bwd_impl(const void* dy, int dy_dtype, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                       const float* rstd, const float* dres, float* dx, int64_t lddx, void* dx_lp, int lp_dtype,
+                       float* dgamma_part, float* dbeta_part, int32_t nparts, float* dgamma, float* dbeta,
+                       int32_t accumulate, int64_t rows, int32_t D, float lp_dropout_p, uint64_t lp_dropout_seed,
+                       const LnQ8& q8, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma_part || !dbeta_part || rows <= 0 || D <= 0 ||
       nparts <= 0)
     return FAVIT_ERR_INVALID;
@@ -620,19 +697,24 @@ extern "C" int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x,
   if ((D & 3) || (ldx & 3) || (lddx & 3)) return FAVIT_ERR_ALIGN;
   if (dy_dtype != lp_dtype && dx_lp) return FAVIT_ERR_UNSUPPORTED;
   if (lp_dropout_p < 0.f || lp_dropout_p >= 1.f) return FAVIT_ERR_INVALID;
+  if (q8.q && (!dx_lp || dy_dtype != FAVIT_BF16)) return FAVIT_ERR_UNSUPPORTED;
   const uint32_t lp_thresh = dx_lp ? dropout_threshold(lp_dropout_p) : 0u;
   const float lp_scale = 1.0f / (1.0f - lp_dropout_p);
   hipStream_t st = as_stream(stream);
   const dim3 grid((unsigned)nparts);
 #define LN_BWD(NV)                                                                                                 \
-  if (dy_dtype == FAVIT_F32)                                                                                       \
+  if (q8.q)                                                                                                        \
+    hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t, NV, true>), grid, dim3(256), 0, st, (const bf16_t*)dy, x,    \
+                       (long)ldx, gamma, mean, rstd, dres, dx, (long)lddx, (bf16_t*)dx_lp, dgamma_part,            \
+                       dbeta_part, (long)rows, D, lp_thresh, lp_scale, lp_dropout_seed, favit_dropout_epoch_ptr_(), q8); \
+  else if (dy_dtype == FAVIT_F32)                                                                                  \
     hipLaunchKernelGGL((ln_bwd_kernel<float, float, NV>), grid, dim3(256), 0, st, (const float*)dy, x, (long)ldx,  \
                        gamma, mean, rstd, dres, dx, (long)lddx, (float*)dx_lp, dgamma_part, dbeta_part, (long)rows, \
-                       D, lp_thresh, lp_scale, lp_dropout_seed, favit_dropout_epoch_ptr_());                                                        \
+                       D, lp_thresh, lp_scale, lp_dropout_seed, favit_dropout_epoch_ptr_(), q8);                   \
   else                                                                                                             \
     hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, bf16_t, NV>), grid, dim3(256), 0, st, (const bf16_t*)dy, x,          \
                        (long)ldx, gamma, mean, rstd, dres, dx, (long)lddx, (bf16_t*)dx_lp, dgamma_part,            \
-                       dbeta_part, (long)rows, D, lp_thresh, lp_scale, lp_dropout_seed, favit_dropout_epoch_ptr_())
+                       dbeta_part, (long)rows, D, lp_thresh, lp_scale, lp_dropout_seed, favit_dropout_epoch_ptr_(), q8)
   LN_DISPATCH_NV(D, LN_BWD);
 #undef LN_BWD
   FAVIT_CHECK_LAUNCH();
@@ -642,6 +724,52 @@ extern "C" int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x,
     FAVIT_CHECK_LAUNCH();
   }
   return FAVIT_OK;
+}
+
+bool lnq8_args_ok(const void* q, int fmt, const float* amax, float* scale_inv, float* amax_next, float* amax_clear) {
+  return q && amax && scale_inv && amax_next && amax_clear && (fmt == FAVIT_E4M3 || fmt == FAVIT_E5M2) &&
+         amax != amax_next && amax != amax_clear && amax_next != amax_clear;
+}
+}  // namespace
+
+extern "C" int favit_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                                   int y_dtype, float* mean, float* rstd, int64_t rows, int32_t D, float eps,
+                                   void* stream) {
+  const LnQ8 off = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  return layernorm_fwd_impl(x, ldx, gamma, beta, y, y_dtype, mean, rstd, rows, D, eps, off, stream);
+}
+
+extern "C" int favit_layernorm_fwd_q8(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                                      float* mean, float* rstd, int64_t rows, int32_t D, float eps, void* q, int fmt,
+                                      const float* amax, float* scale_inv, float* amax_next, float* amax_clear,
+                                      void* stream) {
+  if (!lnq8_args_ok(q, fmt, amax, scale_inv, amax_next, amax_clear)) return FAVIT_ERR_INVALID;
+  const LnQ8 q8 = {reinterpret_cast<uint8_t*>(q), amax, scale_inv, amax_next, amax_clear, fmt};
+  return layernorm_fwd_impl(x, ldx, gamma, beta, y, FAVIT_BF16, mean, rstd, rows, D, eps, q8, stream);
+}
+
+extern "C" int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x, int64_t ldx, const float* gamma,
+                                   const float* mean, const float* rstd, const float* dres, float* dx, int64_t lddx,
+                                   void* dx_lp, int lp_dtype, float* dgamma_part, float* dbeta_part, int32_t nparts,
+                                   float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t D,
+                                   float lp_dropout_p, uint64_t lp_dropout_seed, void* stream) {
+  const LnQ8 off = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  return layernorm_bwd_impl(dy, dy_dtype, x, ldx, gamma, mean, rstd, dres, dx, lddx, dx_lp, lp_dtype, dgamma_part,
+                            dbeta_part, nparts, dgamma, dbeta, accumulate, rows, D, lp_dropout_p, lp_dropout_seed, off,
+                            stream);
+}
+
+extern "C" int favit_layernorm_bwd_q8(const void* dy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                                      const float* rstd, const float* dres, float* dx, int64_t lddx, void* dx_lp,
+                                      float* dgamma_part, float* dbeta_part, int32_t nparts, float* dgamma, float* dbeta,
+                                      int32_t accumulate, int64_t rows, int32_t D, float lp_dropout_p,
+                                      uint64_t lp_dropout_seed, void* q, int fmt, const float* amax, float* scale_inv,
+                                      float* amax_next, float* amax_clear, void* stream) {
+  if (!lnq8_args_ok(q, fmt, amax, scale_inv, amax_next, amax_clear) || !dx_lp) return FAVIT_ERR_INVALID;
+  const LnQ8 q8 = {reinterpret_cast<uint8_t*>(q), amax, scale_inv, amax_next, amax_clear, fmt};
+  return layernorm_bwd_impl(dy, FAVIT_BF16, x, ldx, gamma, mean, rstd, dres, dx, lddx, dx_lp, FAVIT_BF16, dgamma_part,
+                            dbeta_part, nparts, dgamma, dbeta, accumulate, rows, D, lp_dropout_p, lp_dropout_seed, q8,
+                            stream);
 }
 
 extern "C" int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_t rows, int32_t cols,

@@ -385,6 +385,21 @@ def _q8(t: torch.Tensor, fmt: torch.dtype, want_t: bool = False, hist=None):
     return out
 
 
+def _q8_request(chain, prm, which: str, D: int):
+    """fp8 mode: (fp8 dtype, amax history) of the GEMM operand that the tensor a LayerNorm pass is about to write will
+    become -- `which` = "fwd": the chain's input (qkv / fc1 activations, e4m3), "bwd": the gradient of its output (the
+    proj / fc2 input-gradient GEMM's dY, e5m2).  K.layernorm_fwd / _bwd then write the quantised copy in the same pass
+    and park it where _q8 finds it (favit_layernorm_*_q8).  None: not fp8 mode, an unknown chain, a contraction the
+    fp8 GEMM does not take, or no history (graph capture)."""
+    if not _STATE.get("fp8") or get_compute_dtype() != torch.bfloat16 or D % 64 != 0 or os.environ.get("FAVIT_FP8_NO_LNQ8"):
+        return None
+    idx = getattr(chain, "q8_" + which, None)
+    if idx is None or prm is None or idx >= len(prm) or prm[idx] is None:
+        return None
+    hist = _fp8_hist(prm[idx], "a" if which == "fwd" else "dy")
+    return None if hist is None else ((E4M3 if which == "fwd" else E5M2), hist)
+
+
 def _use_fp8(allow, *mats, k_dims=()):
     """fp8 GEMM applies: fp8 mode, bf16 row-major operands, contraction lengths multiples of 64."""
     if not (allow and _STATE.get("fp8")):
@@ -661,6 +676,7 @@ def sdpa_bwd(q: _View, k: _View, v: _View, o: _View, do: _View, dq: _View, dk: _
 # output gradient and returns (dxn [M,D] compute dtype, [param grads in `names` order]).
 # ------------------------------------------------------------------------------------
 class MHLAChain:
+    q8_fwd, q8_bwd = 0, 4        # prm index of the weight whose GEMM consumes the chain's input (qkv) / output gradient (proj)
     """MultiHeadLatentAttention.forward (models/mhla.py:85-161)."""
     names = ("qkv.weight", "qkv.bias", "latent_proj.weight", "latent_proj.bias", "proj.weight", "proj.bias")
 
@@ -734,6 +750,7 @@ class MHLAChain:
 
 
 class DenseChain:
+    q8_fwd, q8_bwd = 0, 2
     """vit.MultiHeadAttention.forward (models/vit.py:77-104) and, with the
     nn.MultiheadAttention parameter names, the use_mhla=False branch
     (models/vit_mhla.py:57-62,96-101).  mask: key-keep [B,L] (torch MHA) or None."""
@@ -843,6 +860,7 @@ class CrossChain:
 
 
 class MLPChain:
+    q8_fwd, q8_bwd = 0, 2
     """MLP.forward fc1 -> GELU -> drop -> fc2 -> drop (models/vit.py:124-139)."""
 
     def __init__(self, p=0.0, fc1="fc1", fc2="fc2"):
@@ -1048,7 +1066,7 @@ class EncoderOp:
                 x1, sa = bs.attn.fwd(None, pa, B, L, x, self.mask, self.training, ln=(x, g1.detach(), b1.detach(), o1), **kw)
                 xn1, mu1, rs1 = o1
             else:
-                xn1, mu1, rs1 = K.layernorm_fwd(x, D, g1, b1, M, D, cdt)
+                xn1, mu1, rs1 = K.layernorm_fwd(x, D, g1, b1, M, D, cdt, q8=_q8_request(bs.attn, pa, "fwd", D))
                 if pre[bi] is not None:
                     x1, sa = bs.attn.fwd(xn1, pa, B, L, x, self.mask, self.training, pre=pre[bi])
                 else:
@@ -1058,9 +1076,9 @@ class EncoderOp:
                 x2, sm = bs.mlp.fwd(None, pm, x1, self.training, ln=(x1, g2.detach(), b2.detach(), o2))
                 xn2, mu2, rs2 = o2
             else:
-                xn2, mu2, rs2 = K.layernorm_fwd(x1, D, g2, b2, M, D, cdt)
+                xn2, mu2, rs2 = K.layernorm_fwd(x1, D, g2, b2, M, D, cdt, q8=_q8_request(bs.mlp, pm, "fwd", D))
                 x2, sm = bs.mlp.fwd(xn2, pm, x1, self.training)
-            tapes.append((x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm))
+            tapes.append((x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm, (pa, pm)))
             x = x2
         return x.reshape(B, L, D), (tapes, B, L, D)
 
@@ -1074,16 +1092,16 @@ class EncoderOp:
         begin_deferred()
         begin_zero_pool(sum(3 * D + 4 for bs in self.blocks if isinstance(bs.attn, MHLAChain)), dy.device)
 
-        def ln_bwd(dxn, xin, gam, bet, mu, rs, dres, pd):
+        def ln_bwd(dxn, xin, gam, bet, mu, rs, dres, pd, q8=None):
             """LayerNorm backward of the stream; the dgamma / dbeta fold joins the deferred batch when the parameters own
-            gradient buffers (the fused-optimizer flow)."""
+            gradient buffers (the fused-optimizer flow).  q8: the low-precision copy also leaves quantised (fp8 mode)."""
             if not gam.requires_grad and not bet.requires_grad:      # frozen layer: no dgamma / dbeta fold at all
-                return K.layernorm_bwd(dxn, xin, D, gam, mu, rs, M, D, dres=dres, want_lp=True, lp_drop=pd, frozen=True)
+                return K.layernorm_bwd(dxn, xin, D, gam, mu, rs, M, D, dres=dres, want_lp=True, lp_drop=pd, frozen=True, q8=q8)
             tg_, tb_ = _gt(gam), _gt(bet)
             lst = _DEFER["ln"] if (_DEFER["on"] and tg_ is not None and tb_ is not None) else None
             n0 = len(lst) if lst is not None else 0
             out = K.layernorm_bwd(dxn, xin, D, gam, mu, rs, M, D, dres=dres, want_lp=True, dg_out=tg_, db_out=tb_,
-                                  lp_drop=pd, defer=lst)
+                                  lp_drop=pd, defer=lst, q8=q8)
             if lst is not None:
                 lst[n0] = lst[n0] + ((gam, bet),)
             elif out[2] is None:
@@ -1096,18 +1114,23 @@ class EncoderOp:
             order = list(zip(reversed(self.blocks), reversed(tapes)))
             premasked = False
             for bi, (bs, tp) in enumerate(order):
-                x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm = tp
+                x, mu1, rs1, (g1, b1), sa, x1, mu2, rs2, (g2, b2), sm, (pa_, _) = tp
                 dxn2, gm = bs.mlp.bwd(sm, g_lp, premasked=premasked)
                 pd = bs.attn.out_dropout(sa) if hasattr(bs.attn, "out_dropout") else (0.0, 0)
-                g, g_lp, dg2, db2 = ln_bwd(dxn2, x1, g2, b2, mu2, rs2, g, pd)
+                # (fp8 mode: the copy feeds this block's proj input-gradient GEMM as its dY -- consumed as it is
+                # written, since a branch with output dropout gets it pre-masked)
+                g, g_lp, dg2, db2 = ln_bwd(dxn2, x1, g2, b2, mu2, rs2, g, pd,
+                                           q8=_q8_request(bs.attn, pa_, "bwd", D) if hasattr(bs.attn, "out_dropout") else None)
                 dxn1, ga = (bs.attn.bwd(sa, g_lp, premasked=pd[0] > 0) if hasattr(bs.attn, "out_dropout")
                             else bs.attn.bwd(sa, g_lp))
                 pd = (0.0, 0)
+                q8n = None
                 if bi + 1 < len(order):
                     nbs, ntp = order[bi + 1]
                     pd = nbs.mlp.out_dropout(ntp[9])
+                    q8n = _q8_request(nbs.mlp, ntp[10][1], "bwd", D)       # the next block's fc2 input-gradient GEMM
                 premasked = pd[0] > 0
-                g, g_lp, dg1, db1 = ln_bwd(dxn1, x, g1, b1, mu1, rs1, g, pd)
+                g, g_lp, dg1, db1 = ln_bwd(dxn1, x, g1, b1, mu1, rs1, g, pd, q8=q8n)
                 if flush_wgrads(force=False) and _STATE["grad_ready"] is not None:
                     flush_deferred()
                 if not _SIDE["enabled"]:

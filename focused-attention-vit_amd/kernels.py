@@ -295,26 +295,53 @@ def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = No
     return out
 
 
-def layernorm_fwd(x, ldx, gamma, beta, rows, D, out_dtype, eps=1e-5):
-    """x: fp32 rows with stride ldx -> y [rows, D] (out_dtype), mean, rstd."""
+def _q8_slots(hist: "Fp8History"):
+    """Rotate a delayed-scaling history by one call: (amax, amax_next, amax_clear) pointers of THIS call."""
+    base, stride = hist.slots.data_ptr(), 4 * hist.NSLOT
+    cur, nxt, clr = hist.calls % 3, (hist.calls + 1) % 3, (hist.calls + 2) % 3
+    hist.calls += 1
+    return C.c_void_p(base + stride * cur), C.c_void_p(base + stride * nxt), C.c_void_p(base + stride * clr)
+
+
+def _q8_fused_ok(q8, out_dtype, D) -> bool:
+    """A LayerNorm pass may quantise its bf16 output for the consumer site: the site has a measured amax (its first
+    call takes the two-pass form, which measures before it scales) and the rows are whole 4-byte groups."""
+    return q8 is not None and q8[1] is not None and q8[1].calls > 0 and out_dtype == torch.bfloat16 and D % 4 == 0
+
+
+def layernorm_fwd(x, ldx, gamma, beta, rows, D, out_dtype, eps=1e-5, q8=None):
+    """x: fp32 rows with stride ldx -> y [rows, D] (out_dtype), mean, rstd.
+    q8 = (fp8 dtype, Fp8History of the consumer GEMM's operand site) in fp8 mode: y also leaves the pass quantised
+    (favit_layernorm_fwd_q8) and the result is parked on the tensor where functional._q8 finds it."""
     require_gpu(x, gamma, beta)
     y = torch.empty((rows, D), dtype=out_dtype, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if _q8_fused_ok(q8, out_dtype, D):
+        fmt, hist = q8
+        q = torch.empty((rows, D), dtype=fmt, device=x.device)
+        sinv = torch.empty(1, dtype=torch.float32, device=x.device)
+        cur, nxt, clr = _q8_slots(hist)
+        _abi.check(_abi.lib().favit_layernorm_fwd_q8(_p(x), ldx, _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, D, eps,
+                                                     _p(q), _abi.E5M2 if fmt == torch.float8_e5m2 else _abi.E4M3, cur,
+                                                     _p(sinv), nxt, clr, _st()), "favit_layernorm_fwd_q8")
+        y._favit_q8 = ((fmt, y._version), (q, None, sinv))
+        return y, mean, rstd
     _abi.check(_abi.lib().favit_layernorm_fwd(_p(x), ldx, _p(gamma), _p(beta), _p(y), dt(y), _p(mean), _p(rstd),
                                               rows, D, eps, _st()), "favit_layernorm_fwd")
     return y, mean, rstd
 
 
 def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None, lddx=None, want_lp=False,
-                  dg_out=None, db_out=None, lp_drop=(0.0, 0), defer=None, frozen=False):
+                  dg_out=None, db_out=None, lp_drop=(0.0, 0), defer=None, frozen=False, q8=None):
     """Returns dx (fp32, row stride lddx), dx_lp (dy.dtype copy or None), dgamma, dbeta.
     dg_out / db_out: optional fp32 [D] gradient buffers the affine gradients are ACCUMULATED into
     (then None is returned in their place).  lp_drop = (p, seed): dx_lp carries that dropout mask (the branch it
     feeds had its output dropped in forward), saving a separate masking pass.
     defer (a list, with dg_out / db_out): the fold of the partial sums into dg_out / db_out is NOT launched; the
     entry (part, dg_out, db_out) is appended and the caller folds several of them in one launch (reduce_rows_multi).
-    frozen: gamma and beta take no gradient (fine-tuning with frozen layers): no fold launch at all, (.., None, None)."""
+    frozen: gamma and beta take no gradient (fine-tuning with frozen layers): no fold launch at all, (.., None, None).
+    q8 = (fp8 dtype, Fp8History) in fp8 mode: dx_lp also leaves the pass quantised (see layernorm_fwd)."""
     require_gpu(dy, x)
     dev = x.device
     if dx is None:
@@ -334,6 +361,18 @@ def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None,
     else:
         dgb = torch.empty((2, D), dtype=torch.float32, device=dev)
         dg, db = dgb[0], dgb[1]
+    if want_lp and _q8_fused_ok(q8, dy.dtype, D):
+        fmt, hist = q8
+        q = torch.empty((rows, D), dtype=fmt, device=dev)
+        sinv = torch.empty(1, dtype=torch.float32, device=dev)
+        cur, nxt, clr = _q8_slots(hist)
+        _abi.check(_abi.lib().favit_layernorm_bwd_q8(_p(dy), _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), lddx,
+                                                     _p(dx_lp), _p(part[0]), _p(part[1]), nparts, _p(dg), _p(db), int(acc), rows, D,
+                                                     float(lp_drop[0]), int(lp_drop[1]) & ((1 << 64) - 1), _p(q),
+                                                     _abi.E5M2 if fmt == torch.float8_e5m2 else _abi.E4M3, cur, _p(sinv), nxt, clr,
+                                                     _st()), "favit_layernorm_bwd_q8")
+        dx_lp._favit_q8 = ((fmt, dx_lp._version), (q, None, sinv))
+        return (dx, dx_lp, None, None) if acc else (dx, dx_lp, dg, db)
     _abi.check(_abi.lib().favit_layernorm_bwd(_p(dy), dt(dy), _p(x), ldx, _p(gamma), _p(mean), _p(rstd), _p(dres),
                                               _p(dx), lddx, _p(dx_lp), dt(dy), _p(part[0]), _p(part[1]), nparts,
                                               _p(dg), _p(db), int(acc), rows, D, float(lp_drop[0]), int(lp_drop[1]) & ((1 << 64) - 1),

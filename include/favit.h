@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FAVIT_ABI_VERSION 7
+#define FAVIT_ABI_VERSION 8
 #define FAVIT_FP8_AMAX_SLOTS 256   /* partial maxima per tensor with delayed fp8 scaling (favit_fp8_quantize) */
 
 enum { FAVIT_F32 = 0, FAVIT_BF16 = 1, FAVIT_FP8 = 2 };
@@ -199,6 +199,21 @@ int favit_layernorm_bwd(const void* dy, int dy_dtype, const float* x, int64_t ld
                         void* dx_lp, int lp_dtype, float* dgamma_part, float* dbeta_part, int32_t nparts,
                         float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t D,
                         float lp_dropout_p, uint64_t lp_dropout_seed, void* stream);
+/* fp8 mode (ABI 8): the same two passes, the bf16 tensor they write (y / dx_lp) ALSO leaving as fp8 in q [rows, D]
+ * (fmt = FAVIT_E4M3 | FAVIT_E5M2) with delayed scaling -- amax / scale_inv / amax_next / amax_clear exactly as in
+ * favit_fp8_quantize (three different arrays of FAVIT_FP8_AMAX_SLOTS floats; all required).  Bytes, scale and
+ * history are bit-identical to favit_layernorm_* followed by favit_fp8_quantize on the bf16 tensor; the stand-alone
+ * pass (one read of the tensor + one write) is what is saved.  y and dy / dx_lp are bf16 here.  No reference
+ * counterpart (the reference is fp32 only); consumers: the fp8 GEMMs of BASELINE.json configs[3]. */
+int favit_layernorm_fwd_q8(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y, float* mean,
+                           float* rstd, int64_t rows, int32_t D, float eps, void* q, int fmt, const float* amax,
+                           float* scale_inv, float* amax_next, float* amax_clear, void* stream);
+int favit_layernorm_bwd_q8(const void* dy, const float* x, int64_t ldx, const float* gamma, const float* mean,
+                           const float* rstd, const float* dres, float* dx, int64_t lddx, void* dx_lp,
+                           float* dgamma_part, float* dbeta_part, int32_t nparts, float* dgamma, float* dbeta,
+                           int32_t accumulate, int64_t rows, int32_t D, float lp_dropout_p, uint64_t lp_dropout_seed,
+                           void* q, int fmt, const float* amax, float* scale_inv, float* amax_next, float* amax_clear,
+                           void* stream);
 /* out[c] (+)= sum_r in[r*ld + c] */
 int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t accumulate,
                       void* stream);

@@ -287,6 +287,59 @@ def test_fp8_training_trajectory_against_oracle(favit):
         favit.functional.clear_lp_mirrors()
 
 
+def test_fp8_steps_are_identical_with_and_without_the_fused_layernorm_quantisation(favit, monkeypatch):
+    """fp8 mode, four steps on fixed weights (learning rate 0: the delayed-scaling histories still rotate, every step
+    sees a batch of another magnitude): with the LayerNorm passes quantising their bf16 outputs (favit_layernorm_*_q8,
+    the default) and with the stand-alone quantising passes (FAVIT_FP8_NO_LNQ8=1) the losses and the LayerNorm
+    gradients of every step are BIT-IDENTICAL and every other gradient agrees to what fp32 atomics allow -- the fused
+    form changes where the bytes are produced, not the bytes; and the fused form really ran (four stand-alone passes
+    per block fewer from the second step on)."""
+    gen = torch.Generator(device=DEV).manual_seed(19)
+    xs = [torch.randn(16, 3, 32, 32, device=DEV, generator=gen) * s for s in (1.0, 2.5, 0.4, 1.5)]
+    ys = [torch.randint(0, 10, (16,), device=DEV, generator=gen) for _ in range(4)]
+    K = favit.kernels
+    out, calls = {}, {}
+    real = K.fp8_quantize
+    try:
+        favit.set_compute_dtype("fp8")
+        for mode in ("fused", "two_pass"):
+            if mode == "two_pass":
+                monkeypatch.setenv("FAVIT_FP8_NO_LNQ8", "1")
+            else:
+                monkeypatch.delenv("FAVIT_FP8_NO_LNQ8", raising=False)
+            n = [0]
+            def counted(*a, _n=n, **kw):
+                _n[0] += 1
+                return real(*a, **kw)
+            monkeypatch.setattr(K, "fp8_quantize", counted)
+            torch.manual_seed(31)
+            m = favit.models.vit_mhla.VisionTransformerMHLA(img_size=32, patch_size=4, num_classes=10, embed_dim=128, depth=3,
+                                                            num_heads=2, window_size=7, use_mhla=True, dropout=0.1).to(DEV).train()
+            opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=0.0), lr=0.0, weight_decay=0.0, distributed=False)
+            steps, per_step = [], []
+            for x, y in zip(xs, ys):
+                before = n[0]
+                loss = favit.train.train_step(m, x, y, opt).item()
+                per_step.append(n[0] - before)
+                steps.append((loss, {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+            out[mode], calls[mode] = steps, per_step
+    finally:
+        monkeypatch.setattr(K, "fp8_quantize", real)
+        favit.set_compute_dtype("fp32")
+        favit.functional.clear_lp_mirrors()
+    for i, ((la, ga), (lb, gb)) in enumerate(zip(out["fused"], out["two_pass"])):
+        assert la == lb, (i, la, lb)
+        for k, a in ga.items():
+            if ".norm" in k:                       # partial sums folded in a fixed order: no atomics anywhere upstream
+                assert torch.equal(a, gb[k]), (i, k)
+            else:
+                assert rel_l2(a, gb[k]) < 1e-5, (i, k)
+    # first step: every site measures first (two passes); afterwards 4 stand-alone passes per block fewer, except the
+    # stream gradient entering the last block from the head (not produced by a LayerNorm backward of the encoder)
+    assert calls["fused"][0] == calls["two_pass"][0]
+    assert calls["two_pass"][-1] - calls["fused"][-1] == 4 * 3 - 1, (calls["fused"], calls["two_pass"])
+
+
 def test_dynamic_lds_limit_grows_with_later_larger_requests():
     """favit_ensure_dyn_lds used to keep the FIRST dynamic-LDS size requested per (kernel, device): a later, larger
     request of the same instantiation (sdpa fp32 hd 256 -> 384, bf16 512 -> 768; MHLA backward hd 128 at L = 197

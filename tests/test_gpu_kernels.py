@@ -806,6 +806,49 @@ def _abi():
     return importlib.import_module("focused-attention-vit_amd")._abi
 
 
+@pytest.mark.parametrize("rows,D", [(1000, 768), (37, 384), (4099, 192)])
+def test_layernorm_passes_quantise_for_the_fp8_gemms(K, rows, D):
+    """favit_layernorm_fwd_q8 / _bwd_q8 (fp8 mode): the bf16 tensor a LayerNorm pass writes also leaves it quantised with
+    the consumer site's delayed scale.  Over four calls with drifting magnitudes (values beyond the previous amax
+    saturate) the bf16 output, the fp8 bytes, the scale and the amax history are BIT-IDENTICAL to the two-pass form
+    (favit_layernorm_* followed by favit_fp8_quantize on the bf16 tensor)."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    gamma = 1 + 0.1 * _rand((D,), torch.float32, g)
+    beta = 0.1 * _rand((D,), torch.float32, g)
+    e4, e5 = torch.float8_e4m3fn, torch.float8_e5m2
+    ha, hb, ga, gb = (K.Fp8History(torch.device(DEV)) for _ in range(4))
+    for step in range(4):
+        amp = (1.0, 3.0, 0.5, 2.0)[step]
+        x = amp * _rand((rows, D), torch.float32, g) + 0.3
+        gam_s = gamma * amp
+        # forward: two passes / one pass
+        y, mu, rs = K.layernorm_fwd(x, D, gam_s, beta, rows, D, torch.bfloat16)
+        q_ref, _, s_ref = K.fp8_quantize(y, e4, hist=ha)
+        y2, mu2, rs2 = K.layernorm_fwd(x, D, gam_s, beta, rows, D, torch.bfloat16, q8=(e4, hb))
+        if step == 0:                                    # no history yet: the site's first call measures first (two passes)
+            assert getattr(y2, "_favit_q8", None) is None
+            q2, _, s2 = K.fp8_quantize(y2, e4, hist=hb)
+        else:
+            q2, _, s2 = y2._favit_q8[1]
+        assert torch.equal(y, y2) and torch.equal(mu, mu2) and torch.equal(rs, rs2)
+        assert torch.equal(q_ref.view(torch.uint8), q2.view(torch.uint8)) and torch.equal(s_ref, s2)
+        assert torch.equal(ha.slots.view(3, -1).max(1).values, hb.slots.view(3, -1).max(1).values) and ha.calls == hb.calls
+        # backward (low-precision copy of the stream gradient, with the dropout mask of the branch it feeds)
+        dy = (amp * _rand((rows, D), torch.float32, g)).to(torch.bfloat16)
+        dres = _rand((rows, D), torch.float32, g)
+        drop = (0.1, 1234 + step) if step % 2 else (0.0, 0)
+        dx, lp, dg, db = K.layernorm_bwd(dy, x, D, gam_s, mu, rs, rows, D, dres=dres, want_lp=True, lp_drop=drop)
+        p_ref, _, t_ref = K.fp8_quantize(lp, e5, hist=ga)
+        dx2, lp2, dg2, db2 = K.layernorm_bwd(dy, x, D, gam_s, mu, rs, rows, D, dres=dres, want_lp=True, lp_drop=drop, q8=(e5, gb))
+        if step == 0:
+            p2, _, t2 = K.fp8_quantize(lp2, e5, hist=gb)
+        else:
+            p2, _, t2 = lp2._favit_q8[1]
+        assert torch.equal(dx, dx2) and torch.equal(lp, lp2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+        assert torch.equal(p_ref.view(torch.uint8), p2.view(torch.uint8)) and torch.equal(t_ref, t2)
+        assert torch.equal(ga.slots.view(3, -1).max(1).values, gb.slots.view(3, -1).max(1).values)
+
+
 @pytest.mark.parametrize("ak,bk", [(True, True), (True, False), (False, True), (False, False)])
 @pytest.mark.parametrize("M,N,Kd", [(50432, 384, 384), (8192 + 40, 1152, 400), (32768 + 4, 200, 64), (36928, 768, 768)])
 @pytest.mark.parametrize("epi", ["plain", "gelu", "dgelu", "res"])

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol(favit):
     for s in declared:
         assert hasattr(lib, s), f"libfavit.so does not export {s}"
     assert set(favit._abi._SIGS) == set(declared), "ctypes signature table out of sync with include/favit.h"
-    assert lib.favit_abi_version() == 7
+    assert lib.favit_abi_version() == 8
     assert lib.favit_strerror(-2).decode().startswith("unsupported")
 
 
