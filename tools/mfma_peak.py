@@ -51,3 +51,22 @@ for wg_per_cu in (1, 2, 4):
     o = out.view(-1, 2).double()
     ghz = (o[:, 0] / o[:, 1]).median().item() * 0.1
     print(f"fp32 32x32x2, {wg_per_cu} wave(s)/SIMD: {us:9.1f} us  {flops / us / 1e6:7.1f} TFLOP/s  clock {ghz:5.2f} GHz", flush=True)
+
+# v_mfma_f32_16x16x4_f32: 2,048 flops per 32 cycles -- the same rate in shorter instructions
+pl.probe_mfma_peak_f32s.argtypes = pl.probe_mfma_peak.argtypes
+for wg_per_cu in (1, 2, 4):
+    blocks = 256 * wg_per_cu
+    out = torch.zeros(2 * blocks, dtype=torch.int64, device=dev)
+    def f32s():
+        assert pl.probe_mfma_peak_f32s(seed32.data_ptr(), iters32, blocks, out.data_ptr(), sink.data_ptr(), st) == 0
+    for _ in range(20): f32s()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): f32s()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    flops = blocks * 4 * iters32 * 16 * (2 * 16 * 16 * 4)
+    o = out.view(-1, 2).double()
+    ghz = (o[:, 0] / o[:, 1]).median().item() * 0.1
+    print(f"fp32 16x16x4, {wg_per_cu} wave(s)/SIMD: {us:9.1f} us  {flops / us / 1e6:7.1f} TFLOP/s  clock {ghz:5.2f} GHz", flush=True)

@@ -250,3 +250,32 @@ extern "C" int probe_mfma_peak_f32(const void* seed, int iters, int blocks, void
                      (unsigned long long*)out, (float*)sink);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---- and for v_mfma_f32_16x16x4_f32 (the same 64 flops per cycle and SIMD in 8-pass instructions, sixteen 4-register accumulators) ----
+__global__ __launch_bounds__(256) void mfma_peak_f32s_kernel(const float* __restrict__ seed, int iters, unsigned long long* out,
+                                                             float* sink) {
+  const int tid = threadIdx.x;
+  float a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = seed[(tid * 8 + i) & 4095]; b[i] = seed[(tid * 8 + 4 + i) & 4095]; }
+  pf32x4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (pf32x4){0.f, 0.f, 0.f, 0.f};
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i & 3], a[i >> 2], acc[i], 0, 0, 0);
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (sum == 12345.678f) sink[0] = sum;
+  if (tid == 0) { out[2 * blockIdx.x] = c1 - c0; out[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+extern "C" int probe_mfma_peak_f32s(const void* seed, int iters, int blocks, void* out, void* sink, void* stream) {
+  hipLaunchKernelGGL(mfma_peak_f32s_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)seed, iters,
+                     (unsigned long long*)out, (float*)sink);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
