@@ -10,7 +10,7 @@
 //     launches with fewer tiles than CUs, "s64ln" (LayerNorm fused, off), "pd" (persistent, deferred epilogue: off)
 //   * "glds": 128x128 tile, direct-to-LDS double buffer (small and batched problems)
 //   * the register-staged 128x128 kernel (any shape / alignment; the fallback)
-// and two exact-fp32 kernels (the parity mode): "p4f", the p4 structure with v_mfma_f32_16x16x4_f32 for the large
+// and two exact-fp32 kernels (the parity mode): "p4f", the p4 structure with v_mfma_f32_32x32x2_f32 for the large
 // problems, and the register-staged 128x128 one.  In the 128x128 kernels a 256-thread workgroup
 // (4 waves, 2x2) owns the tile, each wave a 64x64 sub-tile; operands are consumed from LDS as
 // MFMA fragments:
@@ -2498,49 +2498,51 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(KParams p) {
 }
 
 // --------------------------------------------------------------------------------------
-// f32 kernel "p4f" (round 4): the p4 structure for exact fp32 -- 256x128 (or 128x128) tile, 8 waves (64x64 or 32x64
-// each), BK = 16 (the same 64-byte stage rows, the same 24-KiB stages filled by global_load_lds with counted vmcnt, one
-// raw s_barrier per stage, two workgroups per CU), the wave-private epilogue.  The fp32 MFMA runs at 1/16 of the bf16
-// rate, so this kernel is MFMA-bound by construction: a stage is 2,048 MFMA cycles per wave against 24 KiB of DMA, and a
-// wave reads 8 KiB of fragments per stage.  It replaces the register-staged 128x128 kernel of round 1 (__syncthreads per
-// stage, scalar LDS writes: 0.30-0.41 of the 157 TF peak) for the large GEMMs of the fp32 parity mode.
-// The instruction is v_mfma_f32_16x16x4_f32, NOT 32x32x2: with the four waves per SIMD that two workgroups per CU mean,
-// the bare 32x32x2 loop holds 123.6 TF and the 16x16x4 loop 155.0 TF (tools/mfma_peak.py; both hold 154.6 with one or
-// two waves per SIMD).  Operands swapped as in the bf16 kernels, so the accumulators have their layout and epilogue.
-//   k-major image : p4's ([rows][16 k], 64-B rows, 16-B chunk c at c ^ ksw32(row)); lane (row r = lane & 15, group
-//                   g = lane >> 4) reads ONE 16-byte chunk -- chunk g -- per 16-row block and stage: the instruction's
-//                   four k-slots take k = s, 4 + s, 8 + s, 12 + s in step s (A and B permute k identically);
-//   mn-major image: [16 k][W] floats (W = 256 / 128), k-row kr rotated by 16 * ((kr >> 2) & 3) words so that the four
-//                   lane groups of a fragment read (k-rows s, 4 + s, 8 + s, 12 + s) hit different banks.
+// f32 kernel "p4f" (round 4): the p4 structure for exact fp32 -- 256x128 tile, 8 waves (64x64 each, four
+// v_mfma_f32_32x32x2_f32 accumulator blocks), BK = 16 (the same 64-byte stage rows, the same 24-KiB stages filled by
+// global_load_lds with counted vmcnt, one raw s_barrier per stage, two workgroups per CU), the wave-private epilogue.
+// The fp32 MFMA runs at 1/16 of the bf16 rate, so this kernel is MFMA-bound by construction: a stage is 32 MFMAs of 64
+// cycles per wave against 24 KiB of DMA, and a wave reads 4 KiB of fragments per 1,024 MFMA cycles.  It replaces the
+// register-staged 128x128 kernel of round 1 (__syncthreads per stage, scalar LDS writes: 0.30-0.41 of the 157 TF peak)
+// for the large GEMMs of the fp32 parity mode.
+//   k-major image : p4's ([rows][16 k], 64-B rows, 16-B chunk c at c ^ ksw32(row)); a lane reads ONE 16-byte chunk per
+//                   block row and 8-deep k group: lanes 0-31 chunk 2t, lanes 32-63 chunk 2t+1, i.e. the MFMA's two
+//                   k-slots are k = 8t + s and 8t + 4 + s in step s (A and B permute k identically);
+//   mn-major image: [16 k][W] floats (W = 256 / 128), k-rows whose bit 2 is set rotated by 32 words so that the two
+//                   lane halves of a fragment read (k-rows 8t + s and 8t + 4 + s) hit different banks.
 // --------------------------------------------------------------------------------------
 template <int W>
 __device__ __forceinline__ const char* glds_src_f32_mn(const char* base, long ld, long i0, long I, long k0, int q, int lane) {
   constexpr int LPR = W / 4;                           // lanes (16-byte chunks) per k-row
   const int krow = q * (64 / LPR) + lane / LPR;
   const int pc = lane % LPR;
-  const int c = (pc - 4 * ((krow >> 2) & 3)) & (LPR - 1);
+  const int c = (pc - 8 * ((krow >> 2) & 1)) & (LPR - 1);
   long i = i0 + c * 4;
   const long imax = (I - 4) & ~3L;
   i = i < imax ? i : imax;
   return base + ((k0 + krow) * ld + i) * 4;
 }
 
-template <bool AK, bool BKM, int TBM>
+template <bool AK, bool BKM, int TBM, int NW>
 __device__ __forceinline__ void p4f_body(const KParams& p, int tile, int split) {
   static_assert(TBM == 256 || TBM == 128, "256x128 tiles, or 128x128 ones where those balance better");
-  // (Measured and dropped: four waves per workgroup as 2x2 of 128 / 64 rows -- 8192^3 139.8 TF against 132.5 with the
-  // 32x32x2 instruction, but every shape of the path slower: four waves take twice as long over the epilogue;
-  // s_setprio 1 around the MFMA groups: 8192^3 132.5 -> 108.6 TF.)
+  // NW = 4 (2x2 waves of 128 / 64 rows, 174-182 VGPRs, two waves per SIMD from two workgroups) was measured: 8192^3
+  // 139.8 TF against 132.5 with eight waves, but every shape of the path slower (fc2 forward 587 us against 501, qkv 531
+  // against 445: four waves take twice as long over the epilogue); the bare MFMA loop (tools/mfma_peak.py) holds
+  // 154.6 TF with one or two waves per SIMD and 123.6 TF with four, v_mfma_f32_16x16x4_f32 155.0 TF with four -- but a
+  // 16x16x4 form of this loop (one 16-byte chunk per 16-row block and stage, the bf16 epilogue shared) measured the same
+  // or slower inside the kernel: qkv / fc1 forward 429.5 us against 384.5 in the step, 8192^3 129.6 TF against 132.5.
+  static_assert(NW == 8 || NW == 4, "eight waves as 4x2, or four as 2x2 with twice the rows per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int WR = TBM / 4;                         // rows per wave (the wave tile is WR x 64)
-  constexpr int NI = WR / 16;                         // 16-row accumulator blocks per wave: 4 or 2
-  constexpr int PA = TBM / 16 / 8;                    // 1-KiB DMA pieces of A per wave and stage (B: 1)
+  constexpr int WR = TBM / (NW / 2);                  // rows per wave (the wave tile is WR x 64)
+  constexpr int NI = WR / 32;                         // 32-row accumulator blocks per wave
+  constexpr int PA = TBM / 16 / NW, PB = 8 / NW;      // 1-KiB DMA pieces per wave and stage
   constexpr int A_BYTES = TBM * 64;
   constexpr int STAGE = A_BYTES + P4_B_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int g = lane >> 4, l15 = lane & 15;
+  const int h = lane >> 5, l31 = lane & 31;
 
   const long m0 = (long)(tile / p.tiles_n) * TBM;
   const long n0 = (long)(tile % p.tiles_n) * BN;
@@ -2551,26 +2553,32 @@ __device__ __forceinline__ void p4f_body(const KParams& p, int tile, int split) 
   const long kend = min(p.K, kbeg + p.k_per_split);
   const int nk = (int)((kend - kbeg) / BK32);
 
-  f32x4 acc[4][4];
+  f32x16 acc[NI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const bool do_rowsum = (!AK) && (p.a_rowsum != nullptr) && (n0 == 0) && (wc == 0);
   float rs[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) rs[i] = 0.f;
 
   const char* sa[PA];
-  const char* sb;
+  const char* sb[PB];
 #pragma unroll
   for (int j = 0; j < PA; ++j) {
     const int qa = wave * PA + j;
     if (AK) sa[j] = reinterpret_cast<const char*>(glds_src32<true>(reinterpret_cast<const bf16_t*>(A), 2 * p.lda, m0, p.M, 2 * kbeg, qa, lane));
     else sa[j] = glds_src_f32_mn<TBM>(A, p.lda, m0, p.M, kbeg, qa, lane);
   }
-  if (BKM) sb = reinterpret_cast<const char*>(glds_src32<true>(reinterpret_cast<const bf16_t*>(Bm), 2 * p.ldb, n0, p.N, 2 * kbeg, wave, lane));
-  else sb = glds_src_f32_mn<128>(Bm, p.ldb, n0, p.N, kbeg, wave, lane);
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int qb = wave * PB + j;
+    if (BKM) sb[j] = reinterpret_cast<const char*>(glds_src32<true>(reinterpret_cast<const bf16_t*>(Bm), 2 * p.ldb, n0, p.N, 2 * kbeg, qb, lane));
+    else sb[j] = glds_src_f32_mn<128>(Bm, p.ldb, n0, p.N, kbeg, qb, lane);
+  }
   const long a_step = AK ? 64 : (long)BK32 * p.lda * 4;      // bytes per stage
   const long b_step = BKM ? 64 : (long)BK32 * p.ldb * 4;
   auto issue = [&](int buf) {
@@ -2580,62 +2588,71 @@ __device__ __forceinline__ void p4f_body(const KParams& p, int tile, int split) 
       __builtin_amdgcn_global_load_lds((gptr_t)sa[j], (lptr_t)(st + (wave * PA + j) * 1024), 16, 0, 0);
       sa[j] += a_step;
     }
-    __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(st + A_BYTES + wave * 1024), 16, 0, 0);
-    sb += b_step;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      __builtin_amdgcn_global_load_lds((gptr_t)sb[j], (lptr_t)(st + A_BYTES + (wave * PB + j) * 1024), 16, 0, 0);
+      sb[j] += b_step;
+    }
   };
 
   if (nk > 0) issue(0);
   if (nk > 1) issue(1);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {                                  // the newest stage (PA + 1 pieces of this wave) may still fly
-      if constexpr (PA == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (kt + 1 < nk) {                                  // the newest stage (PA + PB pieces of this wave) may still fly
+      if constexpr (PA + PB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (PA + PB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (PA + PB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + 2 < nk) issue(cur >= 1 ? cur - 1 : 2);
     const char* la = smem + cur * STAGE;
     const char* lb = la + A_BYTES;
-    f32x4 a[NI], b[4];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      if (AK) {
-        const int row = wr * WR + i * 16 + l15;
-        a[i] = *reinterpret_cast<const f32x4*>(la + row * 64 + ((g ^ ksw32(row)) << 4));
-      } else {
-        const float* f = reinterpret_cast<const float*>(la) + (4 * g) * TBM + ((wr * WR + i * 16 + l15 + 16 * g) & (TBM - 1));
-        a[i] = (f32x4){f[0], f[TBM], f[2 * TBM], f[3 * TBM]};
+    for (int t = 0; t < 2; ++t) {
+      f32x4 a[NI], b[2];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (AK) {
+          const int row = wr * WR + i * 32 + l31;
+          a[i] = *reinterpret_cast<const f32x4*>(la + row * 64 + (((2 * t + h) ^ ksw32(row)) << 4));
+        } else {
+          const float* f = reinterpret_cast<const float*>(la) + (8 * t + 4 * h) * TBM + ((wr * WR + i * 32 + l31 + 32 * h) & (TBM - 1));
+          a[i] = (f32x4){f[0], f[TBM], f[2 * TBM], f[3 * TBM]};
+        }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (BKM) {
-        const int row = wc * 64 + j * 16 + l15;
-        b[j] = *reinterpret_cast<const f32x4*>(lb + row * 64 + ((g ^ ksw32(row)) << 4));
-      } else {
-        const float* f = reinterpret_cast<const float*>(lb) + (4 * g) * 128 + ((wc * 64 + j * 16 + l15 + 16 * g) & 127);
-        b[j] = (f32x4){f[0], f[128], f[256], f[384]};
+      for (int j = 0; j < 2; ++j) {
+        if (BKM) {
+          const int row = wc * 64 + j * 32 + l31;
+          b[j] = *reinterpret_cast<const f32x4*>(lb + row * 64 + (((2 * t + h) ^ ksw32(row)) << 4));
+        } else {
+          const float* f = reinterpret_cast<const float*>(lb) + (8 * t + 4 * h) * 128 + ((wc * 64 + j * 32 + l31 + 32 * h) & 127);
+          b[j] = (f32x4){f[0], f[128], f[256], f[384]};
+        }
       }
-    }
+      // (s_setprio 1 around the 8 NI MFMAs of a group, so that the arbiter stays with one wave: 8192^3 132.5 -> 108.6 TF)
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[0][s], a[i][s], acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[1][s], a[i][s], acc[i][1], 0, 0, 0);
+        }
+      if (do_rowsum) {                              // (wave-uniform) bias gradient: the column sums of the mn-major A
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j][s], a[i][s], acc[i][j], 0, 0, 0);
-    if (do_rowsum) {                              // (wave-uniform) bias gradient: the column sums of the mn-major A
-#pragma unroll
-      for (int i = 0; i < NI; ++i) rs[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
+        for (int i = 0; i < NI; ++i) rs[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
+      }
     }
     cur = cur == 2 ? 0 : cur + 1;
   }
   if (do_rowsum) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      float tot = rs[i] + __shfl_xor(rs[i], 16);
-      tot += __shfl_xor(tot, 32);
-      const long m = m0 + wr * WR + i * 16 + l15;
-      if (g == 0 && m < p.M) {
+      const float tot = rs[i] + __shfl_xor(rs[i], 32);
+      const long m = m0 + wr * WR + i * 32 + l31;
+      if (h == 0 && m < p.M) {
         if (p.rowsum_store) p.a_rowsum[m] = tot;
         else atomicAdd(p.a_rowsum + m, tot);
       }
@@ -2643,16 +2660,39 @@ __device__ __forceinline__ void p4f_body(const KParams& p, int tile, int split) 
   }
   __syncthreads();        // every wave is done with the stage buffers; LDS becomes wave-private scratch
   float* wl = reinterpret_cast<float*>(smem + wave * WEPI_BYTES);
+  // deposit a block row (32 rows x 64 columns): a lane holds row (lane & 31), columns 32 j + 8 rg + 4 (lane >> 5) + e
+  auto deposit = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const f32x4 v0 = {c0[4 * rg], c0[4 * rg + 1], c0[4 * rg + 2], c0[4 * rg + 3]};
+      const f32x4 v1 = {c1[4 * rg], c1[4 * rg + 1], c1[4 * rg + 2], c1[4 * rg + 3]};
+      *reinterpret_cast<f32x4*>(wl + l31 * WEPI_LD + 8 * rg + 4 * h) = v0;
+      *reinterpret_cast<f32x4*>(wl + l31 * WEPI_LD + 32 + 8 * rg + 4 * h) = v1;
+    }
+  };
   const long mb = m0 + wr * WR, nb = n0 + wc * 64;
-  wave_epilogue_rows<float, float, 0, 2>(p, acc, C, mb, nb, lane, wl, split == 0, p.alpha);
-  if constexpr (NI == 4) wave_epilogue_rows<float, float, 2, 2>(p, acc, C, mb, nb, lane, wl, split == 0, p.alpha);
+  deposit(acc[0][0], acc[0][1]);
+  wave_epilogue_tail<float, float, 0, 2>(p, C, mb, nb, lane, wl, split == 0, p.alpha);
+  if constexpr (NI >= 2) {
+    deposit(acc[1][0], acc[1][1]);
+    wave_epilogue_tail<float, float, 2, 2>(p, C, mb, nb, lane, wl, split == 0, p.alpha);
+  }
+  if constexpr (NI == 4) {
+    deposit(acc[2][0], acc[2][1]);
+    wave_epilogue_tail<float, float, 4, 2>(p, C, mb, nb, lane, wl, split == 0, p.alpha);
+    deposit(acc[3][0], acc[3][1]);
+    wave_epilogue_tail<float, float, 6, 2>(p, C, mb, nb, lane, wl, split == 0, p.alpha);
+  }
 }
 
 template <bool AK, bool BKM, int TBM>
 __global__ __launch_bounds__(P4_THREADS, 4) void gemm_f32_p4_kernel(KParams p) {
+  // (A phase stagger -- the first-round workgroup in a CU's second slot starting 0.5 / 1 / 1.5 half tiles late, so that
+  // the two workgroups of a CU never sit in their epilogues together -- changed no shape by more than 1 %: measured,
+  // removed.)
   int tile, split;
   tile_and_split(p, tile, split);
-  p4f_body<AK, BKM, TBM>(p, tile, split);
+  p4f_body<AK, BKM, TBM, 8>(p, tile, split);
 }
 
 __global__ void zero_c_kernel(float* C, long M, long N, long ldc, long sCo, long sCi, int batch_inner) {
