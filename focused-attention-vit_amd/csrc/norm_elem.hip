@@ -261,11 +261,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const DyT* __restrict__ dy,
         *reinterpret_cast<float4*>(dx + row * lddx + 4 * i4) = make_float4(o0, o1, o2, o3);
         if (dx_lp) {
           if (lp_thresh) {       // the low-precision copy only feeds a branch whose OUTPUT was dropped: apply that mask here
-            const uint64_t e = (uint64_t)(row * (long)D + 4 * i4);
-            o0 = favit_keep(lp_seed, e, lp_thresh) ? o0 * lp_scale : 0.f;
-            o1 = favit_keep(lp_seed, e + 1, lp_thresh) ? o1 * lp_scale : 0.f;
-            o2 = favit_keep(lp_seed, e + 2, lp_thresh) ? o2 * lp_scale : 0.f;
-            o3 = favit_keep(lp_seed, e + 3, lp_thresh) ? o3 * lp_scale : 0.f;
+            const uint64_t e = (uint64_t)(row * (long)D + 4 * i4);       // (a multiple of 4: D is)
+            bool k0, k1, k2, k3;
+            favit_keep2(lp_seed, e, lp_thresh, k0, k1);
+            favit_keep2(lp_seed, e + 2, lp_thresh, k2, k3);
+            o0 = k0 ? o0 * lp_scale : 0.f;
+            o1 = k1 ? o1 * lp_scale : 0.f;
+            o2 = k2 ? o2 * lp_scale : 0.f;
+            o3 = k3 ? o3 * lp_scale : 0.f;
           }
           store4<LpT>(dx_lp + row * (long)D + 4 * i4, o0, o1, o2, o3);
           if constexpr (Q8)

@@ -43,11 +43,15 @@ run("fwd qkv  NT K=384 N=1152", lambda: K.gemm(x, wqkv, o_qkv, T, 3 * D, D, D, D
 run("fwd fc1  NT K=384 N=1536 gelu", lambda: K.gemm(x, w1, o_h, T, 4 * D, D, D, D, 4 * D, bias=b1, act=A.ACT_GELU, aux_out=o_pre, ld_aux_out=4 * D), 2 * T * 4 * D * D)
 run("fwd fc1  plain bf16 out", lambda: K.gemm(x, w1, o_h, T, 4 * D, D, D, D, 4 * D, bias=b1), 2 * T * 4 * D * D)
 run("fwd fc1  gelu, no saved pre", lambda: K.gemm(x, w1, o_h, T, 4 * D, D, D, D, 4 * D, bias=b1, act=A.ACT_GELU), 2 * T * 4 * D * D)
+run("fwd fc1  gelu+saved derivative", lambda: K.gemm(x, w1, o_h, T, 4 * D, D, D, D, 4 * D, bias=b1, act=A.ACT_GELU_SAVEGRAD, aux_out=o_pre, ld_aux_out=4 * D), 2 * T * 4 * D * D)
+run("fwd fc1  gelu+saved derivative, dropout 0.1", lambda: K.gemm(x, w1, o_h, T, 4 * D, D, D, D, 4 * D, bias=b1, act=A.ACT_GELU_SAVEGRAD, aux_out=o_pre, ld_aux_out=4 * D, dropout_p=0.1, dropout_seed=1234), 2 * T * 4 * D * D)
 run("fwd fc2  NT K=1536 N=384 res", lambda: K.gemm(h, w2, o_d, T, D, 4 * D, 4 * D, 4 * D, D, bias=b2, residual=res, ld_res=D), 2 * T * 4 * D * D)
 run("fwd proj NT K=384 N=384 res", lambda: K.gemm(x, wp, o_d, T, D, D, D, D, D, bias=b2, residual=res, ld_res=D), 2 * T * D * D)
 run("bwd dX   NN K=1152 N=384", lambda: K.gemm(o_qkv, wqkv, o_db, T, D, 3 * D, 3 * D, D, D, b_kmajor=False), 2 * T * 3 * D * D)
 run("bwd dH   NN K=384 N=1536 dgelu", lambda: K.gemm(x, w2, o_h, T, 4 * D, D, D, 4 * D, 4 * D, b_kmajor=False, act=A.ACT_DGELU, aux_in=o_pre, ld_aux_in=4 * D), 2 * T * 4 * D * D)
 run("bwd dH   plain bf16 out", lambda: K.gemm(x, w2, o_h, T, 4 * D, D, D, 4 * D, 4 * D, b_kmajor=False), 2 * T * 4 * D * D)
+run("bwd dH   x saved derivative", lambda: K.gemm(x, w2, o_h, T, 4 * D, D, D, 4 * D, 4 * D, b_kmajor=False, act=A.ACT_MULAUX, aux_in=o_pre, ld_aux_in=4 * D), 2 * T * 4 * D * D)
+run("bwd dH   x saved derivative, dropout 0.1", lambda: K.gemm(x, w2, o_h, T, 4 * D, D, D, 4 * D, 4 * D, b_kmajor=False, act=A.ACT_MULAUX, aux_in=o_pre, ld_aux_in=4 * D, dropout_p=0.1, dropout_seed=1234), 2 * T * 4 * D * D)
 run("bwd dXn2 NN K=1536 N=384", lambda: K.gemm(h, w1, o_db, T, D, 4 * D, 4 * D, D, D, b_kmajor=False), 2 * T * 4 * D * D)
 run("bwd dW1  TN [1536,384]", lambda: K.gemm(h, x, dw1, 4 * D, D, T, 4 * D, D, D, a_kmajor=False, b_kmajor=False, a_rowsum=db), 2 * T * 4 * D * D)
 run("bwd dW2  TN [384,1536]", lambda: K.gemm(x, h, dw2, D, 4 * D, T, D, 4 * D, 4 * D, a_kmajor=False, b_kmajor=False, a_rowsum=db), 2 * T * 4 * D * D)
