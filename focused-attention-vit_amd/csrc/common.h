@@ -96,61 +96,29 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
-// Fast GELU for the bf16 path.  Round 4: the normal CDF is an odd polynomial on a clamped argument,
-//   Phi(x) - 1/2 = t Q(t^2),  t = clamp(x, -4.5, 4.5) / 4.5,  Q of degree 9 (tools/gelu_fit.py: |error| <= 1.1e-5 in
-// fp32 Horner form, GELU itself within 5e-5 -- a fortieth of a bf16 half-ulp at 1), evaluated on PAIRS of elements so
-// that the Horner chain is v_pk_fma_f32 (two FMAs per lane and issue slot): 13 VALU slots per element with GELU'
-// (one v_exp for the density), 23 for the Abramowitz-Stegun form it replaces (v_exp + v_rcp, unpacked).  The GELU
-// epilogues of the 1-workgroup-per-CU kernels are VALU-bound (fc1 at ViT-Base: 252 us with GELU, 199 without).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
-__device__ __forceinline__ f32x2 phi_poly2(f32x2 x) {
-  const f32x2 cl = {__builtin_amdgcn_fmed3f(x.x, -4.5f, 4.5f), __builtin_amdgcn_fmed3f(x.y, -4.5f, 4.5f)};
-  const f32x2 t = cl * (1.0f / 4.5f);
-  const f32x2 u = t * t;
-  f32x2 q = splat2(-4.261638839e+00f);
-  q = fma2(q, u, splat2(2.484848156e+01f));
-  q = fma2(q, u, splat2(-6.462894735e+01f));
-  q = fma2(q, u, splat2(9.980938078e+01f));
-  q = fma2(q, u, splat2(-1.031514738e+02f));
-  q = fma2(q, u, splat2(7.648830515e+01f));
-  q = fma2(q, u, splat2(-4.258644516e+01f));
-  q = fma2(q, u, splat2(1.823896685e+01f));
-  q = fma2(q, u, splat2(-6.051783177e+00f));
-  q = fma2(q, u, splat2(1.795147712e+00f));
-  return fma2(t, q, splat2(0.5f));
-}
-__device__ __forceinline__ f32x2 npdf2(f32x2 x) {                       // exp(-x^2 / 2) / sqrt(2 pi)
-  const f32x2 a = (x * x) * -0.72134752044448170368f;                   // -log2(e) / 2
-  const f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
-  return e * 0.39894228040143267794f;
-}
-__device__ __forceinline__ void gelu_fast2(float& a, float& b) {
-  const f32x2 x = {a, b};
-  const f32x2 h = x * phi_poly2(x);
-  a = h.x; b = h.y;
-}
-__device__ __forceinline__ void dgelu_fast2(float xa, float xb, float& da, float& db) {
-  const f32x2 x = {xa, xb};
-  const f32x2 d = fma2(x, npdf2(x), phi_poly2(x));
-  da = d.x; db = d.y;
-}
-__device__ __forceinline__ void gelu_both_fast2(float& a, float& b, float& da, float& db) {   // a, b -> GELU; da, db <- GELU'
-  const f32x2 x = {a, b};
-  const f32x2 c = phi_poly2(x);
-  const f32x2 h = x * c, d = fma2(x, npdf2(x), c);
-  a = h.x; b = h.y; da = d.x; db = d.y;
+// Fast GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16
+// resolution), one v_exp + one v_rcp instead of libm erff.  phi/Phi share the exponential.
+__device__ __forceinline__ void gelu_terms_fast(float x, float& cdf, float& pdf) {
+  const float ax = fabsf(x);
+  const float e = __expf(-0.5f * x * x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erfa = 1.0f - poly * t * e;            // erf(|x|/sqrt2)
+  cdf = 0.5f * (1.0f + copysignf(erfa, x));
+  pdf = 0.39894228040143267794f * e;
 }
 __device__ __forceinline__ float gelu_fast(float x) {
-  float a = x, b = x;
-  gelu_fast2(a, b);
-  return a;
+  float c, p;
+  gelu_terms_fast(x, c, p);
+  return x * c;
 }
 __device__ __forceinline__ float dgelu_fast(float x) {
-  float a, b;
-  dgelu_fast2(x, x, a, b);
-  return a;
+  float c, p;
+  gelu_terms_fast(x, c, p);
+  return fmaf(x, p, c);
 }
 
 // Counter-based RNG for dropout: the same draw is recomputed in backward, so no mask is stored.  32-bit arithmetic
@@ -159,8 +127,8 @@ __device__ __forceinline__ float dgelu_fast(float x) {
 // (masks of different seeds are not shifted copies of each other), then a 32-bit multiply-xorshift finaliser (the
 // "lowbias32" constants): for a fixed seed the draws of 2^32 consecutive indices are a permutation of the 32-bit values.
 // Round 4: ONE 32-bit draw serves the TWO elements 2i and 2i + 1 (its low / high 16 bits against a 16-bit threshold, so
-// p is realised to 1 / 65536): the two quarter-rate multiplies of the finaliser were the bulk of a dropout epilogue's
-// VALU work (fc1 forward at cfg2: +23 us per launch with dropout 0.1, dH +19 us), and the vector epilogues walk pairs.
+// p is realised to 1 / 65536): the quarter-rate multiplies of the draw were the bulk of a dropout epilogue's VALU work
+// (fc1 forward at cfg2: +23 us per launch with dropout 0.1, dH +19 us; now +8 / +10), and the vector epilogues walk pairs.
 // tests/test_gpu_kernels.py checks keep rates and the absence of correlation across lags, strides and seeds.
 __device__ __forceinline__ uint32_t favit_mix_u32(uint32_t x) {
   x ^= x >> 16;

@@ -258,27 +258,17 @@ template <typename InT> __device__ __forceinline__ float epi_gelu(float v) {
 template <typename InT> __device__ __forceinline__ float epi_dgelu(float v) {
   if constexpr (sizeof(InT) == 2) return dgelu_fast(v); else return dgelu_f(v);
 }
-// GELU and its derivative together (FAVIT_ACT_GELU_SAVEGRAD): one polynomial for Phi, one exponential for phi
+// GELU and its derivative together (FAVIT_ACT_GELU_SAVEGRAD): Phi and phi share the exponential
 template <typename InT> __device__ __forceinline__ void epi_gelu_both(float v, float& h, float& g) {
   if constexpr (sizeof(InT) == 2) {
-    float b = v, gb;
-    h = v;
-    gelu_both_fast2(h, b, g, gb);
+    float c, d;
+    gelu_terms_fast(v, c, d);
+    h = v * c;
+    g = fmaf(v, d, c);
   } else {
     h = gelu_f(v);
     g = dgelu_f(v);
   }
-}
-// the same three on pairs of elements (packed fp32 arithmetic on the low-precision path, common.h)
-template <typename InT> __device__ __forceinline__ void epi_gelu2(float& a, float& b) {
-  if constexpr (sizeof(InT) == 2) gelu_fast2(a, b); else { a = gelu_f(a); b = gelu_f(b); }
-}
-template <typename InT> __device__ __forceinline__ void epi_dgelu2(float xa, float xb, float& da, float& db) {
-  if constexpr (sizeof(InT) == 2) dgelu_fast2(xa, xb, da, db); else { da = dgelu_f(xa); db = dgelu_f(xb); }
-}
-template <typename InT> __device__ __forceinline__ void epi_gelu_both2(float& a, float& b, float& ga, float& gb) {
-  if constexpr (sizeof(InT) == 2) gelu_both_fast2(a, b, ga, gb);
-  else { ga = dgelu_f(a); gb = dgelu_f(b); a = gelu_f(a); b = gelu_f(b); }
 }
 
 template <typename InT, typename OutT, int TBM = BM, int NT = NTHREADS>
@@ -300,10 +290,10 @@ __device__ __forceinline__ void run_epilogue(const KParams& p, const float* epi,
       float ax[4] = {a[0], a[1], a[2], a[3]};            // what aux_out receives: the pre-activation, or GELU'
       if (p.act == FAVIT_ACT_GELU) {
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) epi_gelu2<InT>(a[j], a[j + 1]);
+        for (int j = 0; j < 4; ++j) a[j] = epi_gelu<InT>(a[j]);
       } else if (p.act == FAVIT_ACT_GELU_SAVEGRAD) {
 #pragma unroll
-        for (int j = 0; j < 4; j += 2) epi_gelu_both2<InT>(a[j], a[j + 1], ax[j], ax[j + 1]);
+        for (int j = 0; j < 4; ++j) epi_gelu_both<InT>(a[j], a[j], ax[j]);
       } else if (p.act == FAVIT_ACT_DGELU || p.act == FAVIT_ACT_MULAUX) {
         const InT* ai = reinterpret_cast<const InT*>(p.aux_in) + m * p.ld_aux_in + n;
         float x[4];
@@ -821,23 +811,19 @@ __device__ __forceinline__ void wave_epilogue_tail(const KParams& p, OutT* C, lo
         if (p.act == FAVIT_ACT_GELU_SAVEGRAD) {
           float gd[CPL];
 #pragma unroll
-          for (int c = 0; c < CPL; c += 2) epi_gelu_both2<InT>(a[c], a[c + 1], gd[c], gd[c + 1]);
+          for (int c = 0; c < CPL; ++c) epi_gelu_both<InT>(a[c], a[c], gd[c]);
           if (p.aux_out) store_vec(reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n, gd);
         } else if (p.aux_out) {
           store_vec(reinterpret_cast<OutT*>(p.aux_out) + m * p.ld_aux_out + n, a);
         }
         if (p.act == FAVIT_ACT_GELU) {
 #pragma unroll
-          for (int c = 0; c < CPL; c += 2) epi_gelu2<InT>(a[c], a[c + 1]);
+          for (int c = 0; c < CPL; ++c) a[c] = epi_gelu<InT>(a[c]);
         } else if (p.act == FAVIT_ACT_DGELU) {
 #pragma unroll
           for (int c4 = 0; c4 < CPL / 4; ++c4)
 #pragma unroll
-            for (int c = 0; c < 4; c += 2) {
-              float d0, d1;
-              epi_dgelu2<InT>((float)aux[it & 1][c4][c], (float)aux[it & 1][c4][c + 1], d0, d1);
-              a[4 * c4 + c] *= d0; a[4 * c4 + c + 1] *= d1;
-            }
+            for (int c = 0; c < 4; ++c) a[4 * c4 + c] *= epi_dgelu<InT>((float)aux[it & 1][c4][c]);
         } else if (p.act == FAVIT_ACT_MULAUX) {
 #pragma unroll
           for (int c4 = 0; c4 < CPL / 4; ++c4)
