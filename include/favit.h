@@ -88,6 +88,8 @@ int favit_set_health_word(uint32_t* device_words);
  *   act=GELU: v=gelu_erf(v) (models/vit.py:135); act=DGELU: v*=gelu'(aux_in[m,n]).
  *   dropout_p>0: v = keep(seed, m*N+n) ? v/(1-p) : 0  (nn.Dropout sites models/vit.py:102,
  *   136,138, models/mhla.py:159; the same (seed,index) draw is reused by the backward GEMMs).
+ *   keep(seed, i): one 32-bit counter-based draw per element PAIR (i >> 1); element i takes its low (i even) or high
+ *   16 bits and is kept when they are >= floor(p * 65536) -- p is realised to 1 / 65536, in every kernel of the library.
  * accumulate=1 (or split_k>1) adds into C with fp32 atomics; C must then be FAVIT_F32.
  * a_rowsum (a_kmajor=0 only): a_rowsum[m] += sum_k A[m,k]  (bias gradient, fused).
  * Batched: z in [0,batch): ptr += (z / batch_inner) * s?o + (z % batch_inner) * s?i.
