@@ -220,10 +220,11 @@ class DeviceLoader:
                 self.prep_stream.wait_event(ev)
                 x = self.tf(d_img)
                 maps = self.segmenter.segment_device(x)
+                derived = self.segmenter.derive_for(maps)        # patch mapping + centroids: functions of the maps alone
                 d_img.record_stream(self.prep_stream)
                 ev2 = torch.cuda.Event()
                 ev2.record(self.prep_stream)
-            return (x, maps), d_lab, ev2
+            return (x, maps, derived), d_lab, ev2
         return d_img, d_lab, ev
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
@@ -247,14 +248,17 @@ class DeviceLoader:
         cs.wait_event(ev)                                 # device-side wait, the host does not block
         d_lab.record_stream(cs)
         if self.segmenter is not None:
-            x, maps = d_img
+            x, maps, derived = d_img
             x.record_stream(cs)
             maps.record_stream(cs)
-            # the model's next segment() call returns them; a captured step reads the installed tensor in place
+            for tens in derived.values():
+                for t_ in tens:
+                    t_.record_stream(cs)
+            # the model's next segment() call returns them; a captured step reads the installed tensors in place
             if getattr(self.segmenter, "_captured", False) and self.segmenter._maps is not None:
-                self.segmenter.update_label_maps(maps)
+                self.segmenter.update_label_maps(maps, derived)
             else:
-                self.segmenter.set_label_maps(maps)
+                self.segmenter.set_label_maps(maps, derived)
             return x, d_lab
         d_img.record_stream(cs)
         return self.tf(d_img), d_lab

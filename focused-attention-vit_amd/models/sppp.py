@@ -20,6 +20,49 @@ from ._backend import F, K, params
 from .vit import PatchEmbedding, TransformerBlock as _VitBlock, run_encoder
 
 
+class _MapState:
+    """Installed label maps + what depends on them alone: the patch -> superpixel mapping (rank, token counts, permutation,
+    offsets: `PatchToSuperpixelMapper.map_patches_batched`) and the superpixel centroids, per (patch size, superpixel
+    count) that a model asked for.  The reference recomputes both inside every forward
+    (models/sppp_mhla.py:287-291, 307); neither depends on a weight, so here they are computed once per INSTALL of the
+    maps (by data.DeviceLoader on its preparation stream, under the previous step) instead of inside every step
+    (three launches, ~68 us of a 2.4-ms cfg3 step).  `version` is the maps tensor's version the derived tensors belong
+    to: an in-place edit of the maps that bypasses update_label_maps is noticed by the next eager forward and by
+    train.GraphedStep before a replay, and the derived tensors are refreshed IN PLACE (a captured graph holds their
+    addresses)."""
+
+    def __init__(self, maps: torch.Tensor, derived=None):
+        self.maps = maps
+        self.derived = {k: list(v) for k, v in (derived or {}).items()}
+        self.version = maps._version
+
+    @staticmethod
+    def derive(maps: torch.Tensor, P: int, S: int):
+        rank, ntok, perm, offs, _ = K.sppp_map_patches(maps, P)
+        return [rank, ntok, perm, offs, K.sppp_centroids(maps, S)]
+
+    def refresh_if_stale(self, derived=None):
+        if self.maps._version == self.version and derived is None:
+            return
+        for key, dst in self.derived.items():
+            src = derived.get(key) if derived else None
+            if src is None:
+                src = self.derive(self.maps, *key)
+            for d, s_ in zip(dst, src):
+                d.copy_(s_, non_blocking=True)
+        self.version = self.maps._version
+
+    def get(self, P: int, S: int):
+        key = (int(P), int(S))
+        if key not in self.derived:
+            if self.maps._version != self.version:
+                self.refresh_if_stale()
+            self.derived[key] = self.derive(self.maps, *key)
+        elif self.maps._version != self.version:
+            self.refresh_if_stale()
+        return self.derived[key]
+
+
 class SuperpixelSegmentation:
     """reference models/sppp.py:26-74"""
 
@@ -27,24 +70,37 @@ class SuperpixelSegmentation:
         self.num_segments = num_segments
         self.compactness = compactness
         self.sigma = sigma
-        self._maps = None
+        self._state: Optional[_MapState] = None
+        self._keys = set()             # (patch size, superpixel count) pairs models have asked the derived tensors for
         self._captured = False         # a train.GraphedStep has captured the ADDRESS of the installed maps
         self.rescale_input = True      # scikit-image >= 0.19 rescales every image to [0, 1] first; False = < 0.19
 
-    def set_label_maps(self, maps: Optional[torch.Tensor]):
-        """Install precomputed label maps [B,H,W] (int64) returned by the next segment() calls.  A train.GraphedStep
-        captured earlier keeps reading (and keeps alive) the tensor that was installed at ITS capture: to change what
-        such a step sees, use update_label_maps."""
-        self._maps = maps
+    @property
+    def _maps(self) -> Optional[torch.Tensor]:
+        return None if self._state is None else self._state.maps
 
-    def update_label_maps(self, maps: torch.Tensor):
+    def set_label_maps(self, maps: Optional[torch.Tensor], derived=None):
+        """Install precomputed label maps [B,H,W] (int64) returned by the next segment() calls.  A train.GraphedStep
+        captured earlier keeps reading (and keeps alive) the tensors that were installed at ITS capture: to change what
+        such a step sees, use update_label_maps.  derived: what `derive_for(maps)` returned (data.DeviceLoader computes
+        it on its own stream); otherwise the first forward computes it."""
+        self._state = None if maps is None else _MapState(maps, derived)
+
+    def update_label_maps(self, maps: torch.Tensor, derived=None):
         """Copy new label maps INTO the installed tensor (same shape): the form a captured training step needs, whose
         replayed kernels read the installed tensor's address (data.DeviceLoader does this per batch once a step has
-        been captured)."""
-        if self._maps is None or tuple(maps.shape) != tuple(self._maps.shape) or maps.device != self._maps.device:
+        been captured).  The tensors derived from the maps are refreshed in place as well (from `derived` if given)."""
+        st = self._state
+        if st is None or tuple(maps.shape) != tuple(st.maps.shape) or maps.device != st.maps.device:
             raise RuntimeError("update_label_maps: install maps of this shape with set_label_maps first")
-        if maps is not self._maps:
-            self._maps.copy_(maps.to(self._maps.dtype), non_blocking=True)
+        if maps is not st.maps:
+            st.maps.copy_(maps.to(st.maps.dtype), non_blocking=True)
+        st.refresh_if_stale(derived if derived else None)
+
+    def derive_for(self, maps: torch.Tensor) -> dict:
+        """The patch mapping / centroid tensors of `maps` for every (patch size, superpixel count) a model has asked this
+        object for so far, on the current stream (data.DeviceLoader: its preparation stream)."""
+        return {k: _MapState.derive(maps, *k) for k in sorted(self._keys)}
 
     def segment_device(self, images: torch.Tensor) -> torch.Tensor:
         """Device SLIC of a batch [B,3,H,W] on the current stream, ignoring installed maps (data.DeviceLoader calls it
@@ -166,11 +222,18 @@ class DynamicPositionalEncoding(nn.Module):
 def sppp_tokens(model, x: torch.Tensor) -> torch.Tensor:
     """Shared front end of the SPPP models (models/sppp_mhla.py:274-310): label maps -> patch
     embedding -> device-side patch->superpixel mapping + pooling -> CLS -> centroid pos-enc."""
-    seg = model.segmentation.segment(x)
+    sg = model.segmentation
+    seg = sg.segment(x)
     if seg.device != x.device:
         seg = seg.to(x.device)
     tok = model.patch_embed(x)
-    rank, ntok, perm, offs, _ = model.patch_mapper.map_patches_batched(seg)
+    st = sg._state
+    if st is not None and seg is st.maps and x.dim() == 4:          # installed maps: mapping + centroids once per install
+        rank, ntok, perm, offs, cent_pre = st.get(model.patch_mapper.patch_size, model.num_superpixels)
+        sg._keys.add((int(model.patch_mapper.patch_size), int(model.num_superpixels)))
+    else:
+        rank, ntok, perm, offs, _ = model.patch_mapper.map_patches_batched(seg)
+        cent_pre = None
     R = getattr(model, "assume_num_tokens", None)
     if R is None:
         lo, hi = int(ntok.min().item()), int(ntok.max().item())      # one host sync; skip via assume_num_tokens
@@ -180,7 +243,7 @@ def sppp_tokens(model, x: torch.Tensor) -> torch.Tensor:
         R = lo
     pooled = model.pooling.pool_batched(tok, perm, offs, R)
     t = F.run(F.PrologueOp(False), [pooled], [model.cls_token])
-    cent = K.sppp_centroids(seg, model.num_superpixels)
+    cent = cent_pre if cent_pre is not None else K.sppp_centroids(seg, model.num_superpixels)
     return model.pos_embed(t, cent)
 
 
@@ -221,24 +284,24 @@ class TokenBucketed(nn.Module):
         groups = {}
         for i, c in enumerate(counts):
             groups.setdefault(int(c), []).append(i)
-        installed, assumed = seg_host._maps, getattr(m, "assume_num_tokens", None)
+        installed, assumed = seg_host._state, getattr(m, "assume_num_tokens", None)
         if seg_host._captured:
             raise RuntimeError("TokenBucketed: the wrapped model's label maps are captured by a GraphedStep")
         try:
             if len(groups) == 1:
-                seg_host._maps, m.assume_num_tokens = maps, next(iter(groups))
+                seg_host._state, m.assume_num_tokens = _MapState(maps), next(iter(groups))
                 return m(x)
             order, outs = [], []
             for c in sorted(groups):
                 idx = torch.tensor(groups[c], device=x.device, dtype=torch.int64)
-                seg_host._maps, m.assume_num_tokens = maps.index_select(0, idx), c
+                seg_host._state, m.assume_num_tokens = _MapState(maps.index_select(0, idx)), c
                 outs.append(m(x.index_select(0, idx)))
                 order += groups[c]
             inv = torch.empty(len(order), dtype=torch.int64)
             inv[torch.tensor(order)] = torch.arange(len(order))
             return torch.cat(outs, 0).index_select(0, inv.to(x.device))
         finally:
-            seg_host._maps, m.assume_num_tokens = installed, assumed
+            seg_host._state, m.assume_num_tokens = installed, assumed
 
 
 def calculate_superpixel_centroids(model, segmentation_maps: torch.Tensor) -> torch.Tensor:

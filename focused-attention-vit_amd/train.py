@@ -213,11 +213,15 @@ class GraphedStep:
     and for SPPP models ``model.assume_num_tokens`` set (the per-forward token-count check is a host sync)."""
 
     def __init__(self, model: torch.nn.Module, opt: FusedAdamW, images: torch.Tensor, labels: torch.Tensor,
-                 warmup: int = 3, segments: Optional[int] = None):
+                 warmup: int = 3, segments: Optional[int] = None, static_inputs: bool = False):
+        """static_inputs: `images` / `labels` themselves are the buffers the captured kernels read (no clone at capture,
+        no copy per call when the step is called with these same tensors): for a producer that writes every batch into
+        fixed device buffers (bench.py's resident synthetic batch).  Default: private copies, one device-to-device copy
+        of the batch per call."""
         if K.GEMM_TRACE is not None:
             raise RuntimeError("GraphedStep: disable kernels.GEMM_TRACE (event records cannot be captured)")
         self.model, self.opt = model, opt
-        self.x, self.y = images.clone(), labels.clone()
+        self.x, self.y = (images, labels) if static_inputs else (images.clone(), labels.clone())
         syncs = [g["sync"] for g in opt.groups if g["sync"] is not None and g["sync"]._active]
         self._syncs = syncs
         if segments is None:
@@ -259,11 +263,12 @@ class GraphedStep:
         # the split-K slab workspace (kernels.py keeps outgrown ones) -- and the installed label maps (their content is
         # changed with SuperpixelSegmentation.update_label_maps; data.DeviceLoader does so once a step is captured).
         self._keep = [K._GROUPED_WS.get(self.x.device.index)]
+        self._map_states = []          # label maps + the tensors derived from them (models/sppp.py::_MapState)
         for mod in model.modules():
             seg = getattr(mod, "segmentation", None)
-            if seg is not None and getattr(seg, "_maps", None) is not None:
+            if seg is not None and getattr(seg, "_state", None) is not None:
                 seg._captured = True
-                self._keep.append(seg._maps)
+                self._map_states.append(seg._state)
 
     def _forward_backward(self, graphs):
         """zero_grad + forward + loss, then backward piece by piece; with a list, every piece is captured in a graph of
@@ -303,6 +308,8 @@ class GraphedStep:
         if labels is not self.y:
             self.y.copy_(labels, non_blocking=True)
         self.opt.refresh_mirrors()         # (host-side version check; a cast only after an outside edit of the weights)
+        for st in self._map_states:        # (likewise: label maps edited in place without update_label_maps)
+            st.refresh_if_stale()
         self.graphs[0].replay()
         for g, ready in zip(self.graphs[1:], self._ready):
             g.replay()

@@ -179,6 +179,68 @@ def test_token_bucketed_runs_batches_with_different_token_counts(favit):
     m.segmentation.set_label_maps(None)
 
 
+def test_sppp_map_derived_tensors_follow_the_installed_maps(favit):
+    """The patch -> superpixel mapping and the centroids depend on the label maps alone and are computed once per
+    install (models/sppp.py::_MapState; the reference recomputes them in every forward, models/sppp_mhla.py:287-307).
+    An in-place edit of the installed maps -- with update_label_maps or behind its back -- is followed: by the next eager
+    forward, and by a captured step before its next replay.  Logits / losses equal those of a fresh install."""
+    torch.manual_seed(23)
+    S = 64
+    mk = lambda: favit.models.sppp_mhla.SPPPViTMHLA(img_size=S, patch_size=8, num_classes=10, embed_dim=64, depth=2, num_heads=4,
+                                                    num_superpixels=4, pooling_type="mean", window_size=3, use_mhla=True).to(DEV).train()
+    m, ref = mk(), mk()
+    ref.load_state_dict(m.state_dict())
+    ar = torch.arange(S)
+    quad = ((ar[:, None] >= S // 2).long() * 2 + (ar[None, :] >= S // 2).long())
+    other = ((ar[:, None] >= S // 4).long() * 2 + (ar[None, :] >= 3 * S // 4).long())       # four regions, other borders
+    mapsA = quad.expand(4, S, S).contiguous().to(DEV)
+    mapsB = other.expand(4, S, S).contiguous().to(DEV)
+    x = torch.randn(4, 3, S, S, device=DEV)
+    y = torch.tensor([1, 4, 0, 9], device=DEV)
+    installed = mapsA.clone()
+    m.segmentation.set_label_maps(installed)
+    ref.segmentation.set_label_maps(mapsA)
+    assert rel_l2(m(x).detach(), ref(x).detach()) < 1e-6
+    st = m.segmentation._state
+    derived_before = [t.data_ptr() for t in st.get(8, 4)]
+    installed.copy_(mapsB)                                           # behind update_label_maps' back
+    ref.segmentation.set_label_maps(mapsB)
+    assert rel_l2(m(x).detach(), ref(x).detach()) < 1e-6
+    assert [t.data_ptr() for t in st.get(8, 4)] == derived_before     # refreshed in place
+    m.segmentation.update_label_maps(mapsA)
+    ref.segmentation.set_label_maps(mapsA)
+    assert rel_l2(m(x).detach(), ref(x).detach()) < 1e-6
+    # a captured step: its replays read the derived tensors at fixed addresses
+    for mm in (m, ref):
+        mm.assume_num_tokens = 4
+    opt = favit.train.FusedAdamW(favit.train.param_groups(m, lr=0.0), lr=0.0, weight_decay=0.0, distributed=False)
+    ropt = favit.train.FusedAdamW(favit.train.param_groups(ref, lr=0.0), lr=0.0, weight_decay=0.0, distributed=False)
+    step = favit.train.GraphedStep(m, opt, x, y)
+    for maps, how in ((mapsB, "copy"), (mapsA, "update"), (mapsB, "update")):
+        if how == "copy":
+            installed.copy_(maps)
+        else:
+            m.segmentation.update_label_maps(maps)
+        ref.segmentation.set_label_maps(maps)
+        got = step(x, y).item()
+        want = favit.train.train_step(ref, x, y, ropt).item()
+        assert abs(got - want) < 1e-5 * max(1.0, abs(want)), (how, got, want)
+    # static_inputs: the caller's tensors ARE the captured buffers -- no clone, no copy per call; new batches are written
+    # into them in place (bench.py's resident batch)
+    xs, ys = x.clone(), y.clone()
+    step2 = favit.train.GraphedStep(m, opt, xs, ys, static_inputs=True)
+    assert step2.x is xs and step2.y is ys
+    for k in range(2):
+        xs.copy_(torch.randn_like(xs))
+        ys.copy_(torch.randint(0, 10, ys.shape, device=DEV))
+        got = step2(xs, ys).item()
+        want = favit.train.train_step(ref, xs, ys, ropt).item()
+        assert abs(got - want) < 1e-5 * max(1.0, abs(want)), (k, got, want)
+    m.segmentation.set_label_maps(None)
+    ref.segmentation.set_label_maps(None)
+    favit.functional.clear_lp_mirrors()
+
+
 def test_sppp_reference_dict_api(favit):
     c = case(SP, "vor16")
     seg = torch.from_numpy(c["segmap"].astype(np.int64)).to(DEV)
