@@ -173,6 +173,13 @@ def test_token_bucketed_runs_batches_with_different_token_counts(favit):
     assert rel_l2(logits.detach(), torch.cat(rows)) < 1e-5
     for k, p in m.named_parameters():
         assert p.grad is not None and rel_l2(got[k], p.grad) < 2e-4, k
+    # ... and what the ORACLE (the reference's algorithm, oracle/favit_oracle.py) gives for each image alone
+    from oracle import favit_oracle as O
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want = torch.cat([O.sppp_vit_mhla_forward(x[i:i + 1].cpu(), maps[i:i + 1].cpu().numpy(), sd, 8, 4, 3, True, S=4, kind="mean")
+                          for i in range(6)])
+    assert rel_l2(logits.detach().cpu(), want) < 1e-3
     # a batch with one count goes through in one piece
     m.segmentation.set_label_maps(maps[[0, 2, 5]].contiguous())
     assert rel_l2(wrapped(x[[0, 2, 5]]).detach(), torch.cat([rows[0], rows[2], rows[5]])) < 1e-5
