@@ -24,6 +24,29 @@ def synthetic_dataset(n, classes, size, seed):
     return x, y
 
 
+def synthetic_blocks_dataset(n, classes, size, grid, seed, sample_seed=None):
+    """Synthetic images for the SPPP experiment: a grid x grid board of flat colour blocks (a class-specific palette,
+    per-sample brightness jitter per block).  SLIC finds exactly grid^2 superpixels on such an image, which is what the
+    reference's forward needs from every image of a batch (torch.stack, models/sppp_mhla.py:300; the positional
+    encoding accepts num_superpixels or num_superpixels - 1 regions, models/sppp.py:299) -- random-noise prototypes give
+    1..16 regions per image and the reference's forward (and this one) raises on the first batch."""
+    rs = np.random.RandomState(seed)
+    # block colours well apart from their neighbours: a coarse lattice of base colours shuffled per class
+    base = np.array([[r, g, b] for r in (40, 128, 215) for g in (40, 128, 215) for b in (40, 128, 215)], dtype=np.int32)
+    pal = np.stack([base[rs.permutation(len(base))[:grid * grid]] for _ in range(classes)])        # [classes, g*g, 3]
+    if sample_seed is not None:                          # (same palettes, other samples: the test split)
+        rs = np.random.RandomState(sample_seed)
+    y = rs.randint(0, classes, size=n)
+    jit = rs.randint(-12, 13, size=(n, grid * grid, 1))
+    blocks = np.clip(pal[y] + jit, 0, 255).astype(np.uint8).reshape(n, grid, grid, 3)
+    cell = size // grid
+    x = np.repeat(np.repeat(blocks, cell, axis=1), cell, axis=2)
+    if x.shape[1] != size:                               # size not a multiple of the grid: pad by edge replication
+        pad = size - x.shape[1]
+        x = np.pad(x, ((0, 0), (0, pad), (0, pad), (0, 0)), mode="edge")
+    return x, y
+
+
 def batches(x, y, bs, shuffle, rs):
     idx = rs.permutation(len(x)) if shuffle else np.arange(len(x))
     return [(x[idx[i:i + bs]], y[idx[i:i + bs]]) for i in range(0, len(x) - bs + 1, bs)]
@@ -68,9 +91,20 @@ def main():
         xtr, ytr, xte, yte = d["x_train"], d["y_train"], d["x_test"], d["y_test"]
     else:
         src = 32 if a.dataset == "cifar10" else a.img_size
-        xtr, ytr = synthetic_dataset(2048, 10, src, a.seed)
-        xte, yte = synthetic_dataset(512, 10, src, a.seed)       # same prototypes (same seed), fresh noise below
-        xte = np.clip(xte.astype(np.int32) + rs.randint(-10, 11, size=xte.shape), 0, 255).astype(np.uint8)
+        grid = int(round(a.num_superpixels ** 0.5))
+        if a.experiment == "sppp_mhla" and grid * grid == a.num_superpixels:
+            xtr, ytr = synthetic_blocks_dataset(2048, 10, src, grid, a.seed)
+            xte, yte = synthetic_blocks_dataset(512, 10, src, grid, a.seed, sample_seed=a.seed + 1)
+            if a.compactness == 0.1:
+                # with the reference's colour-dominated default, blocks of similar colour merge and an image yields
+                # 10..17 regions (measured); a spatially dominated SLIC returns the board's grid^2 cells for every image
+                a.compactness = 200.0
+                print("synthetic block images: SLIC compactness set to 200 (every image then yields "
+                      f"{a.num_superpixels} superpixels; pass --compactness to override)")
+        else:
+            xtr, ytr = synthetic_dataset(2048, 10, src, a.seed)
+            xte, yte = synthetic_dataset(512, 10, src, a.seed)       # same prototypes (same seed), fresh noise below
+            xte = np.clip(xte.astype(np.int32) + rs.randint(-10, 11, size=xte.shape), 0, 255).astype(np.uint8)
     classes = int(max(ytr.max(), yte.max())) + 1
     M = pkg.models
     kw = dict(img_size=a.img_size, patch_size=a.patch_size, num_classes=classes, embed_dim=a.embed_dim, depth=a.depth,
