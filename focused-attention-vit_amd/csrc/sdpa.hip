@@ -8,7 +8,8 @@
 // MFMA (bf16: v_mfma_f32_16x16x32_bf16; fp32 parity mode: the exact-fp32 v_mfma_f32_16x16x4_f32), the softmax
 // runs in registers with wave shuffles (online, one (max, sum) pair per row), and the forward only stores O and
 // the row log-sum-exp.  The backward recomputes the probabilities from Q, K and that log-sum-exp (two kernels,
-// no atomics, deterministic): dQ per query tile, (dK, dV) per key tile, delta = rowsum(dO * O).
+// no atomics, deterministic): dQ per query tile (which also computes delta = rowsum(dO * O) of its rows), then (dK, dV)
+// per key tile.
 //
 // One device function serves the three kernels.  An "owner" tile (64 rows, 16 per wave; the rows whose output is
 // accumulated) meets "streamed" rows in blocks of 32 staged in LDS:
@@ -38,6 +39,9 @@ struct SdpaArgs {
   void* out1;           //                            MODE 2: dv
   float* lse;           // [B*H, Lq]  (written by MODE 0, read by 1 / 2)
   const float* delta;   // [B*H, Lq]  rowsum(dO * O)
+  float* delta_out;     // MODE 1 (round 4): the dQ pass computes delta of its owner rows itself and publishes it here
+  const void* o;        //   for the dK / dV pass that follows it on the stream (no sdpa_delta_kernel launch: 6 us x 12
+  View vo;              //   per cfg1 step); o = the forward's output
   const uint8_t* mask;
   long m_sb, m_sq;
   View vq, vk, vv, vdo, vo0, vo1;
@@ -214,7 +218,30 @@ __global__ __launch_bounds__(320) void sdpa_kernel(SdpaArgs a) {      // 4 or 5 
   for (int dt = 0; dt < NDT; ++dt) { acc0[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   float m_run = -INFINITY, l_run = 0.f;                // MODE 0: online softmax state of the owner (query) row
   float lse_o = 0.f, delta_o = 0.f;                    // MODE 1: the owner row's statistics
-  if (MODE == 1) { lse_o = a.lse[zq + onc]; delta_o = a.delta[zq + onc]; }
+  if (MODE == 1) {
+    lse_o = a.lse[zq + onc];
+    if (a.delta_out) {
+      // delta_i = sum_d dO[i, d] * O[i, d] of the owner row: the four lanes of a row take the k-slices g of every chunk
+      const T* o_row = reinterpret_cast<const T*>(a.o) + b * a.vo.sb + h * a.vo.sh + (long)onc * a.vo.ld;
+      float dsum = 0.f;
+      const int nch = (hd + M::KC - 1) / M::KC;
+      for (int c = 0; c < nch; ++c) {
+        const typename M::frag fd = M::slice_global(ob_row, c, g, hd), fo = M::slice_global(o_row, c, g, hd);
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dsum = fmaf((float)fd[j], (float)fo[j], dsum);
+        } else {
+          dsum = fmaf(fd, fo, dsum);
+        }
+      }
+      dsum += __shfl_xor(dsum, 16);
+      dsum += __shfl_xor(dsum, 32);
+      delta_o = dsum;
+      if (g == 0 && on < Lo && blockIdx.z == 0) a.delta_out[zq + on] = dsum;
+    } else {
+      delta_o = a.delta[zq + onc];
+    }
+  }
   const uint8_t* mrow_b = a.mask ? a.mask + (long)b * a.m_sb : nullptr;
   const int nchunk = hd_pad / M::KC;
 
@@ -401,24 +428,6 @@ __global__ __launch_bounds__(320) void sdpa_kernel(SdpaArgs a) {      // 4 or 5 
   }
 }
 
-// delta[z, i] = sum_d dO[i, d] * O[i, d]   (one wave per row)
-template <typename T>
-__global__ __launch_bounds__(256) void sdpa_delta_kernel(const T* __restrict__ o, View vo, const T* __restrict__ dout, View vdo,
-                                                         float* __restrict__ delta, int H, int Lq, int hd, long rows) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long row = (long)blockIdx.x * 4 + wave;
-  if (row >= rows) return;
-  const long z = row / Lq;
-  const int i = (int)(row - z * Lq);
-  const int b = (int)(z / H), h = (int)(z % H);
-  const T* orow = o + b * vo.sb + h * vo.sh + (long)i * vo.ld;
-  const T* grow = dout + b * vdo.sb + h * vdo.sh + (long)i * vdo.ld;
-  float s = 0.f;
-  for (int d = lane; d < hd; d += 64) s = fmaf(to_f32(orow[d]), to_f32(grow[d]), s);
-  s = wave_sum(s);
-  if (lane == 0) delta[row] = s;
-}
-
 template <typename T, int MODE>
 int launch_mode(const SdpaArgs& a_in, hipStream_t st) {
   SdpaArgs a = a_in;
@@ -488,6 +497,7 @@ SdpaArgs base_args(const favit_sdpa_t* s) {
   a.q = s->q; a.k = s->k; a.v = s->v; a.dout = s->dout;
   a.out0 = nullptr; a.out1 = nullptr;
   a.lse = s->lse; a.delta = s->delta;
+  a.delta_out = nullptr; a.o = s->o; a.vo = view(s->o_str);
   a.mask = s->mask; a.m_sb = (long)s->m_sb; a.m_sq = (long)s->m_sq;
   a.vq = view(s->q_str); a.vk = view(s->k_str); a.vv = view(s->v_str); a.vdo = view(s->do_str);
   a.vo0 = view(s->o_str); a.vo1 = view(s->o_str);
@@ -515,19 +525,13 @@ extern "C" int favit_sdpa_bwd(const favit_sdpa_t* s, void* stream) {
   int rc = check(s, true);
   if (rc != FAVIT_OK) return rc;
   hipStream_t st = as_stream(stream);
-  const long rows = (long)s->B * s->H * s->Lq;
-  const dim3 dg((unsigned)((rows + 3) / 4));
-  if (s->dtype == FAVIT_BF16)
-    hipLaunchKernelGGL((sdpa_delta_kernel<bf16_t>), dg, dim3(256), 0, st, (const bf16_t*)s->o, view(s->o_str), (const bf16_t*)s->dout,
-                       view(s->do_str), s->delta, s->H, s->Lq, s->hd, rows);
-  else
-    hipLaunchKernelGGL((sdpa_delta_kernel<float>), dg, dim3(256), 0, st, (const float*)s->o, view(s->o_str), (const float*)s->dout,
-                       view(s->do_str), s->delta, s->H, s->Lq, s->hd, rows);
-  FAVIT_CHECK_LAUNCH();
+  // (delta = rowsum(dO * O) is computed by the dQ pass for its owner rows and read by the dK / dV pass behind it)
   SdpaArgs a = base_args(s);
   a.out0 = s->dq; a.vo0 = view(s->dq_str);
+  a.delta_out = s->delta;
   rc = s->dtype == FAVIT_BF16 ? launch_mode<bf16_t, 1>(a, st) : launch_mode<float, 1>(a, st);
   if (rc != FAVIT_OK) return rc;
+  a.delta_out = nullptr;
   a.out0 = s->dk; a.vo0 = view(s->dk_str);
   a.out1 = s->dv; a.vo1 = view(s->dv_str);
   return s->dtype == FAVIT_BF16 ? launch_mode<bf16_t, 2>(a, st) : launch_mode<float, 2>(a, st);
