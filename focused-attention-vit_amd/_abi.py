@@ -71,6 +71,8 @@ _SIGS = {
     "favit_layernorm_fwd_q8": ([vp, i64, vp, vp, vp, vp, vp, i64, i32, f32, vp, C.c_int, vp, vp, vp, vp, vp], C.c_int),
     "favit_layernorm_bwd_q8": ([vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp, i32, i64, i32, f32, u64,
                                 vp, C.c_int, vp, vp, vp, vp, vp], C.c_int),
+    "favit_small_linear_fwd": ([vp, i64, vp, vp, vp, i32, i32, i32, vp], C.c_int),
+    "favit_small_linear_bwd": ([vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, vp], C.c_int),
     "favit_reduce_rows": ([vp, i64, vp, i64, i32, i32, vp], C.c_int),
     "favit_reduce_rows_multi": ([i32, vp, vp, vp, i64, i32, vp], C.c_int),
     "favit_mhla_fold_fwd": ([vp, vp, vp, vp, vp, C.c_int, vp, vp, i32, i32, vp], C.c_int),

@@ -775,6 +775,92 @@ extern "C" int favit_layernorm_bwd_q8(const void* dy, const float* x, int64_t ld
                             stream);
 }
 
+// ---------------------------------------------------------------------------------
+// Classification head (nn.Linear(D, num_classes) on the normalised CLS row: models/vit.py:259,306,
+// models/vit_mhla.py:156,249, models/sppp_mhla.py:240,318): M = batch rows, N = a few classes.  As a GEMM it is ONE
+// 128x128 tile -- a single workgroup walking K in 64-deep steps, 13-21 us per launch, three launches plus two casts per
+// step (3.7 % of the cfg1 step).  Here: exact fp32 dot products on the VALU, one launch forward, one backward, no
+// atomics (deterministic), 3-4 us each.
+// ---------------------------------------------------------------------------------
+namespace {
+constexpr int SL_MAX_N = 64;
+
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, long ldx,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int N, int K) {
+  const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* xr = x + (long)m * ldx;
+  for (int n = wave; n < N; n += 4) {
+    const float* wr = w + (long)n * K;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(xr[k], wr[k], s);
+    s = wave_sum(s);
+    if (lane == 0) y[(long)m * N + n] = s + (bias ? bias[n] : 0.f);
+  }
+}
+
+// blocks [0, M): dx rows (if dx); blocks [M, M + N): one weight row each (+ its bias gradient)
+__global__ __launch_bounds__(256) void small_linear_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               long ldx, const float* __restrict__ w,
+                                                               float* __restrict__ dx, float* __restrict__ dw,
+                                                               float* __restrict__ db, int accumulate, int M, int N,
+                                                               int K) {
+  __shared__ float sh[SL_MAX_N > 256 ? SL_MAX_N : 256];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < M) {
+    if (!dx) return;
+    const int m = blockIdx.x;
+    if (tid < N) sh[tid] = dy[(long)m * N + tid];
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) s = fmaf(sh[n], w[(long)n * K + k], s);
+      dx[(long)m * K + k] = s;
+    }
+    return;
+  }
+  const int n = blockIdx.x - M;
+  float bsum = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 256) {
+    const int k = k0 + tid;
+    float s = 0.f;
+    for (int m0 = 0; m0 < M; m0 += 256) {              // dy[:, n] of 256 rows through LDS, x read coalesced along k
+      __syncthreads();
+      const int mm = m0 + tid;
+      sh[tid] = mm < M ? dy[(long)mm * N + n] : 0.f;
+      __syncthreads();
+      const int cnt = min(256, M - m0);
+      if (k < K)
+        for (int i = 0; i < cnt; ++i) s = fmaf(sh[i], x[(long)(m0 + i) * ldx + k], s);
+      if (k0 == 0 && tid == 0)
+        for (int i = 0; i < cnt; ++i) bsum += sh[i];
+    }
+    if (k < K) dw[(long)n * K + k] = accumulate ? dw[(long)n * K + k] + s : s;
+  }
+  if (db && tid == 0) db[n] = accumulate ? db[n] + bsum : bsum;
+}
+}  // namespace
+
+extern "C" int favit_small_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int32_t M,
+                                      int32_t N, int32_t K, void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K) return FAVIT_ERR_INVALID;
+  if (N > SL_MAX_N) return FAVIT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3(M), dim3(256), 0, as_stream(stream), x, (long)ldx, w, bias, y, N, K);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
+extern "C" int favit_small_linear_bwd(const float* dy, const float* x, int64_t ldx, const float* w, float* dx, float* dw,
+                                      float* db, int32_t accumulate, int32_t M, int32_t N, int32_t K, void* stream) {
+  if (!dy || !x || !w || !dw || M <= 0 || N <= 0 || K <= 0 || ldx < K) return FAVIT_ERR_INVALID;
+  if (N > SL_MAX_N) return FAVIT_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(small_linear_bwd_kernel, dim3(M + N), dim3(256), 0, as_stream(stream), dy, x, (long)ldx, w, dx, dw, db,
+                     accumulate, M, N, K);
+  FAVIT_CHECK_LAUNCH();
+  return FAVIT_OK;
+}
+
 extern "C" int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_t rows, int32_t cols,
                                  int32_t accumulate, void* stream) {
   if (!in || !out || rows <= 0 || cols <= 0) return FAVIT_ERR_INVALID;

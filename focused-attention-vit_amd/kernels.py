@@ -332,6 +332,36 @@ def layernorm_fwd(x, ldx, gamma, beta, rows, D, out_dtype, eps=1e-5, q8=None):
     return y, mean, rstd
 
 
+SMALL_LINEAR_MAX_N = 64
+
+
+def small_linear_fwd(x, w, bias):
+    """y = x @ w.T + bias in exact fp32 (x [M, K] fp32 contiguous rows, w [N, K] fp32, N <= 64): the classification head."""
+    require_gpu(x, w)
+    M, Kd = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _abi.check(_abi.lib().favit_small_linear_fwd(_p(x), x.stride(0), _p(w), _p(bias), _p(y), M, N, Kd, _st()),
+               "favit_small_linear_fwd")
+    return y
+
+
+def small_linear_bwd(dy, x, w, *, want_dx=True, dw_out=None, db_out=None, want_db=True):
+    """(dx or None, dw or None, db or None) of small_linear_fwd.  dw_out / db_out: fp32 gradient buffers the results are
+    ACCUMULATED into (then None is returned in their place)."""
+    require_gpu(dy, x, w)
+    M, Kd = x.shape
+    N = w.shape[0]
+    dev = x.device
+    dx = torch.empty((M, Kd), dtype=torch.float32, device=dev) if want_dx else None
+    acc = dw_out is not None and (db_out is not None or not want_db)
+    dw = dw_out if acc else torch.empty((N, Kd), dtype=torch.float32, device=dev)
+    db = (db_out if acc else torch.empty(N, dtype=torch.float32, device=dev)) if want_db else None
+    _abi.check(_abi.lib().favit_small_linear_bwd(_p(dy), _p(x), x.stride(0), _p(w), _p(dx), _p(dw), _p(db), int(acc), M, N, Kd,
+                                                 _st()), "favit_small_linear_bwd")
+    return dx, (None if acc else dw), (None if (acc or not want_db) else db)
+
+
 def layernorm_bwd(dy, x, ldx, gamma, mean, rstd, rows, D, *, dres=None, dx=None, lddx=None, want_lp=False,
                   dg_out=None, db_out=None, lp_drop=(0.0, 0), defer=None, frozen=False, q8=None):
     """Returns dx (fp32, row stride lddx), dx_lp (dy.dtype copy or None), dgamma, dbeta.

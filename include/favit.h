@@ -216,6 +216,15 @@ int favit_layernorm_bwd_q8(const void* dy, const float* x, int64_t ldx, const fl
                            int32_t accumulate, int64_t rows, int32_t D, float lp_dropout_p, uint64_t lp_dropout_seed,
                            void* q, int fmt, const float* amax, float* scale_inv, float* amax_next, float* amax_clear,
                            void* stream);
+/* The classification head as exact-fp32 dot products (ABI 8): y[M,N] = x[M,K] (row stride ldx) . w[N,K]^T + bias, and its
+ * backward dx[M,K] (NULL: skipped) = dy . w, dw[N,K] (+)= dy^T . x, db[N] (NULL: skipped) (+)= column sums of dy
+ * (accumulate = 1 adds to dw / db).  N <= 64 (FAVIT_ERR_UNSUPPORTED beyond: those heads are GEMMs); no atomics.
+ * Reference: nn.Linear(embed_dim, num_classes) on the normalised CLS row, models/vit.py:259,306,
+ * models/vit_mhla.py:156,249, models/sppp_mhla.py:240,318. */
+int favit_small_linear_fwd(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int32_t M, int32_t N,
+                           int32_t K, void* stream);
+int favit_small_linear_bwd(const float* dy, const float* x, int64_t ldx, const float* w, float* dx, float* dw, float* db,
+                           int32_t accumulate, int32_t M, int32_t N, int32_t K, void* stream);
 /* out[c] (+)= sum_r in[r*ld + c] */
 int favit_reduce_rows(const float* in, int64_t ld, float* out, int64_t rows, int32_t cols, int32_t accumulate,
                       void* stream);

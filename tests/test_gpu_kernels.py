@@ -806,6 +806,33 @@ def _abi():
     return importlib.import_module("focused-attention-vit_amd")._abi
 
 
+@pytest.mark.parametrize("M,N,Kd", [(128, 10, 192), (256, 10, 384), (300, 64, 1000), (1, 3, 7), (64, 1000 // 16, 768)])
+def test_small_linear_head_kernels(K, M, N, Kd):
+    """favit_small_linear_fwd / _bwd (the classification head as exact-fp32 dot products, one launch each way): against
+    fp64, from zero and accumulating into existing gradient buffers, with and without dx / bias."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = _rand((M, Kd), torch.float32, g)
+    w = _rand((N, Kd), torch.float32, g)
+    b = _rand((N,), torch.float32, g)
+    dy = _rand((M, N), torch.float32, g)
+    y = K.small_linear_fwd(x, w, b)
+    assert rel_l2(y.double(), x.double() @ w.double().t() + b.double()) < 1e-6
+    assert rel_l2(K.small_linear_fwd(x, w, None).double(), x.double() @ w.double().t()) < 1e-6
+    dx, dw, db = K.small_linear_bwd(dy, x, w)
+    assert rel_l2(dx.double(), dy.double() @ w.double()) < 1e-6
+    assert rel_l2(dw.double(), dy.double().t() @ x.double()) < 1e-6
+    assert rel_l2(db.double(), dy.double().sum(0)) < 1e-6
+    gw, gb = dw.clone(), db.clone()
+    dx2, dw2, db2 = K.small_linear_bwd(dy, x, w, want_dx=False, dw_out=gw, db_out=gb)
+    assert dx2 is None and dw2 is None and db2 is None
+    assert rel_l2(gw.double(), 2 * dy.double().t() @ x.double()) < 1e-6 and rel_l2(gb.double(), 2 * dy.double().sum(0)) < 1e-6
+    dx3, dw3, db3 = K.small_linear_bwd(dy, x, w, want_db=False)
+    assert db3 is None and torch.equal(dw3, dw) and torch.equal(dx3, dx)
+    # a strided row view (x[:, 0] of a [M, L, K] stream) is accepted as it is
+    big = _rand((M, 3, Kd), torch.float32, g)
+    assert rel_l2(K.small_linear_fwd(big[:, 0], w, b).double(), big[:, 0].double() @ w.double().t() + b.double()) < 1e-6
+
+
 @pytest.mark.parametrize("rows,D", [(1000, 768), (37, 384), (4099, 192)])
 def test_layernorm_passes_quantise_for_the_fp8_gemms(K, rows, D):
     """favit_layernorm_fwd_q8 / _bwd_q8 (fp8 mode): the bf16 tensor a LayerNorm pass writes also leaves it quantised with
